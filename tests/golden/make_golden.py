@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the real reference (kch3782/torcwa 0.1.4.2).
+
+Run only in the build container, where /root/reference exists:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes small .npz fixtures next to this file.  Nothing of the reference's source travels:
+the fixtures are inputs + the reference's numerical outputs.  The GPU box only reads the .npz.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+import torcwa  # noqa: E402  (the reference)
+
+assert torcwa.__version__ == "0.1.4.2"
+torch.set_num_threads(8)
+
+ORDERS_PROBE = [[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [-1, -1], [2, 1], [99, -99]]   # last one clamps
+POLS = ["xx", "yx", "xy", "yy", "pp", "sp", "ps", "ss"]
+DIRPORT = [("forward", "transmission"), ("forward", "reflection"), ("backward", "reflection"), ("backward", "transmission")]
+
+
+def asih_nk(lams):
+    """n+ik of a-Si:H from the reference's example helper (example/Materials.py), c128."""
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "example"))
+    sys.path.insert(0, os.path.join(REF, "example"))
+    import Materials
+    out = []
+    for lam in lams:
+        out.append(complex(Materials.aSiH.apply(torch.tensor(float(lam), dtype=torch.float64))))
+    os.chdir(cwd)
+    return np.array(out, dtype=np.complex128)
+
+
+def ref_geometry(nx, ny, Lx, Ly, dtype):
+    g = torcwa.geometry(Lx=Lx, Ly=Ly, nx=nx, ny=ny, edge_sharpness=1000., dtype=dtype, device=torch.device("cpu"))
+    g.grid()
+    return g
+
+
+def run_case(name, *, freq, order, L, layers, dtype, eps_in=None, eps_out=None, inc=0.0, azi=0.0,
+             angle_layer="input", full_S=False, extra=None, avoid=False):
+    """layers: list of (thickness, eps, mu) with eps/mu python scalars or torch grids."""
+    cdt = torch.complex128 if dtype == "c128" else torch.complex64
+    rdt = torch.float64 if dtype == "c128" else torch.float32
+    sim = torcwa.rcwa(freq=freq, order=order, L=L, dtype=cdt, device=torch.device("cpu"),
+                      stable_eig_grad=False, avoid_Pinv_instability=avoid)
+    if eps_in is not None:
+        sim.add_input_layer(eps=eps_in)
+    if eps_out is not None:
+        sim.add_output_layer(eps=eps_out)
+    sim.set_incident_angle(inc_ang=inc, azi_ang=azi, angle_layer=angle_layer)
+    for (d, eps, mu) in layers:
+        e = eps.to(cdt if torch.is_complex(eps) else rdt) if torch.is_tensor(eps) else eps
+        m = mu.to(cdt if torch.is_complex(mu) else rdt) if torch.is_tensor(mu) else mu
+        sim.add_layer(thickness=d, eps=e, mu=m)
+    sim.solve_global_smatrix()
+
+    out = {"freq": np.float64(freq), "order": np.array(order), "L": np.array(L, dtype=np.float64),
+           "inc": np.float64(inc), "azi": np.float64(azi), "angle_layer": angle_layer,
+           "has_in": eps_in is not None, "has_out": eps_out is not None,
+           "eps_in": np.complex128(eps_in if eps_in is not None else 1.0),
+           "eps_out": np.complex128(eps_out if eps_out is not None else 1.0),
+           "n_layers": len(layers)}
+    for li, (d, eps, mu) in enumerate(layers):
+        out[f"L{li}_thickness"] = np.float64(d)
+        for nm, v in (("eps", eps), ("mu", mu)):
+            if torch.is_tensor(v):
+                out[f"L{li}_{nm}_grid"] = v.numpy()
+            else:
+                out[f"L{li}_{nm}_scalar"] = np.complex128(v)
+    N = sim.order_N
+    n = 2 * N
+    out["kx"] = sim.Kx_norm_dn.numpy()
+    out["ky"] = sim.Ky_norm_dn.numpy()
+    # S-parameters: 8 pols x 4 (dir, port) x probe orders
+    sp = np.zeros((len(DIRPORT), len(POLS), len(ORDERS_PROBE)), dtype=np.complex128)
+    for a, (dr, pt) in enumerate(DIRPORT):
+        for b, pol in enumerate(POLS):
+            if sim.S[1].dim() == 1 and (dr, pt) in (("forward", "reflection"), ("backward", "reflection")) and eps_in is None and eps_out is None:
+                continue
+            v = sim.S_parameters(orders=[list(o) for o in ORDERS_PROBE], direction=dr, port=pt, polarization=pol, ref_order=[0, 0])
+            sp[a, b] = v.numpy()
+    out["sparams"] = sp
+    # same with ref_order=(1,0)-ish and no power norm for the xy branch (exercise index/normalisation paths)
+    v = sim.S_parameters(orders=[list(o) for o in ORDERS_PROBE], direction="f", port="t", polarization="yx", ref_order=[-1, 1], power_norm=False)
+    out["sparams_yx_ref_m1p1_nonorm"] = v.numpy()
+    v = sim.S_parameters(orders=[list(o) for o in ORDERS_PROBE], direction="f", port="r", polarization="ps", ref_order=[0, 1])
+    out["sparams_ps_ref_0p1_refl"] = v.numpy()
+    S = [x.numpy() for x in sim.S]
+    out["S_fro"] = np.array([np.linalg.norm(x) for x in S])
+    # central sub-block |m|,|n|<=1, both polarisations
+    oy = order[1]
+    cidx = [(2 * oy + 1) * (m + order[0]) + (q + oy) for m in (-1, 0, 1) if abs(m) <= order[0] for q in (-1, 0, 1) if abs(q) <= oy]
+    cidx = np.array(cidx + [c + N for c in cidx])
+    out["central_idx"] = cidx
+    for k in range(4):
+        if S[k].ndim == 2:
+            out[f"S{k}_central"] = S[k][np.ix_(cidx, cidx)]
+            if full_S:
+                out[f"S{k}"] = S[k]
+    for li in range(len(layers)):
+        kz = sim.kz_norm[li].numpy()
+        lam = kz ** 2
+        idx = np.lexsort((lam.imag, lam.real))
+        out[f"L{li}_kz2_sorted"] = lam[idx]
+        if full_S:
+            out[f"L{li}_E"] = sim.eps_conv[li].numpy()
+            out[f"L{li}_P"] = sim.P[li].numpy()
+            out[f"L{li}_Q"] = sim.Q[li].numpy()
+            out[f"L{li}_S11"] = sim.layer_S11[li].numpy()
+            out[f"L{li}_S21"] = sim.layer_S21[li].numpy()
+            out[f"L{li}_S12"] = sim.layer_S12[li].numpy()
+            out[f"L{li}_S22"] = sim.layer_S22[li].numpy()
+    if full_S:
+        out["Vf"] = sim.Vf.numpy()
+        if eps_in is not None:
+            for k in range(4):
+                out[f"Sin{k}"] = sim.Sin[k].numpy()
+        if eps_out is not None:
+            for k in range(4):
+                out[f"Sout{k}"] = sim.Sout[k].numpy()
+    if avoid:
+        out["Pinv_instability"] = np.array([float(x) for x in sim.Pinv_instability])
+        out["Qinv_instability"] = np.array([float(x) for x in sim.Qinv_instability])
+    # diffraction angles (a small piece of host glue, rcwa.py:214-262)
+    ia, aa = sim.diffraction_angle(orders=[list(o) for o in ORDERS_PROBE], layer="output", unit="degree")
+    out["diff_inc_deg"], out["diff_azi_deg"] = ia.numpy(), aa.numpy()
+    if extra:
+        out.update(extra(sim))
+    path = os.path.join(HERE, f"{name}_{dtype}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}_{dtype}: n={n}  txx00={sp[0, 0, 0]:.12g}  -> {os.path.getsize(path) / 1024:.0f} KiB")
+    return sim
+
+
+def main():
+    lam_tab = np.concatenate([np.linspace(400., 700., 128), [532., 650.]])
+    nk = asih_nk(lam_tab)
+    np.savez_compressed(os.path.join(HERE, "asih_table.npz"), lam=lam_tab, nk=nk)
+    eps_si = {532.: complex(nk[-2] ** 2), 650.: complex(nk[-1] ** 2)}
+    print("eps_Si(532) =", eps_si[532.], " eps_Si(650) =", eps_si[650.])
+
+    for dtype in ("c128", "c64"):
+        rdt = torch.float64 if dtype == "c128" else torch.float32
+        # --- Fresnel, no internal layer (Example0): glass -> air, 0/30/60 degrees ------------
+        for ang in (0, 30, 60):
+            run_case(f"fresnel_{ang}", freq=1 / 532., order=[2, 2], L=[300., 300.], layers=[], dtype=dtype,
+                     eps_in=1.46 ** 2, inc=ang * np.pi / 180, full_S=(ang == 30))
+        # --- Example1 rectangle, 1 layer, 300x300 grid --------------------------------------
+        g = ref_geometry(300, 300, 300., 300., torch.float64)
+        rect = g.rectangle(Wx=180., Wy=100., Cx=150., Cy=150.)
+        eps1 = rect * eps_si[532.] + (1. - rect)
+        for o in ([3, 3], [5, 5]):
+            # store the density recipe, not the 300x300 grid (checksum pins it)
+            sim = run_case(f"example1_o{o[0]}", freq=1 / 532., order=o, L=[300., 300.], dtype=dtype,
+                           layers=[(300., eps1, 1.0)], eps_in=1.46 ** 2, full_S=(o[0] == 3))
+        # --- Example2: 15 deg oblique incidence, square 120 ---------------------------------
+        sq = g.square(W=120., Cx=150., Cy=150.)
+        eps2 = sq * eps_si[532.] + (1. - sq)
+        run_case("example2_o4", freq=1 / 532., order=[4, 4], L=[300., 300.], dtype=dtype,
+                 layers=[(300., eps2, 1.0)], eps_in=1.46 ** 2, inc=15 * np.pi / 180)
+        # --- Example1-1: literal 6-layer stack at 650 nm ------------------------------------
+        su8 = 1.6 ** 2
+        lays = []
+        for th in (0., 30., 60.):
+            r = g.rectangle(Wx=180., Wy=100., Cx=150., Cy=150., theta=th / 180 * np.pi)
+            lays.append((200., r * eps_si[650.] + (1. - r) * su8, 1.0))
+            lays.append((100., su8, 1.0))
+        run_case("example1_1_o4", freq=1 / 650., order=[4, 4], L=[300., 300.], dtype=dtype, layers=lays, eps_in=1.46 ** 2)
+        # --- asymmetric case: order [3,2], L=[320,410], 40x36 complex grids, patterned eps AND mu,
+        #     oblique + azimuth, input and output half-spaces, angle referenced to the output layer.
+        gen = torch.Generator().manual_seed(20260927)
+        ge = torch.rand(40, 36, generator=gen, dtype=torch.float64)
+        gm = torch.rand(40, 36, generator=gen, dtype=torch.float64)
+        epsg = (1.0 + 5.0 * ge) + 1j * (0.3 * ge)
+        mug = (1.0 + 0.4 * gm) + 0j
+        gen2 = torch.Generator().manual_seed(7)
+        g2 = torch.rand(40, 36, generator=gen2, dtype=torch.float64)
+        eps_real = 1.0 + 3.0 * g2
+        run_case("asym_o32", freq=1 / 600., order=[3, 2], L=[320., 410.], dtype=dtype,
+                 layers=[(150., epsg, mug), (80., 2.25, 1.0), (120., eps_real, 1.0)],
+                 eps_in=2.1, eps_out=1.7, inc=20 * np.pi / 180, azi=35 * np.pi / 180, angle_layer="output", full_S=True)
+        run_case("asym_o32_avoidPinv", freq=1 / 600., order=[3, 2], L=[320., 410.], dtype=dtype,
+                 layers=[(150., epsg, mug)], eps_in=2.1, inc=20 * np.pi / 180, azi=35 * np.pi / 180, avoid=True)
+
+    # geometry recipe pin: the oracle's rectangle_density must reproduce this
+    g = ref_geometry(300, 300, 300., 300., torch.float64)
+    rect = g.rectangle(Wx=180., Wy=100., Cx=150., Cy=150.).numpy()
+    rect30 = g.rectangle(Wx=180., Wy=100., Cx=150., Cy=150., theta=30 / 180 * np.pi).numpy()
+    np.savez_compressed(os.path.join(HERE, "geometry_pin.npz"),
+                        rect_sum=rect.sum(), rect_crc=np.uint32(zlib.crc32(rect.tobytes())),
+                        rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
+
+
+if __name__ == "__main__":
+    main()

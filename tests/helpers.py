@@ -1,0 +1,53 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+ORDERS_PROBE = [[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [-1, -1], [2, 1], [99, -99]]
+POLS = ["xx", "yx", "xy", "yy", "pp", "sp", "ps", "ss"]
+DIRPORT = [("forward", "transmission"), ("forward", "reflection"), ("backward", "reflection"), ("backward", "transmission")]
+
+CASES = ["fresnel_0", "fresnel_30", "fresnel_60", "example1_o3", "example1_o5", "example2_o4",
+         "example1_1_o4", "asym_o32", "asym_o32_avoidPinv"]
+
+
+def load_case(name, dtype):
+    z = np.load(os.path.join(GOLDEN, f"{name}_{dtype}.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def case_inputs(g, dtype):
+    """Rebuild the exact inputs the reference was given (see tests/golden/make_golden.py:run_case)."""
+    cdt = torch.complex128 if dtype == "c128" else torch.complex64
+    rdt = torch.float64 if dtype == "c128" else torch.float32
+    layers = []
+    for li in range(int(g["n_layers"])):
+        vals = []
+        for nm in ("eps", "mu"):
+            if f"L{li}_{nm}_grid" in g:
+                t = torch.from_numpy(g[f"L{li}_{nm}_grid"])
+                t = t.to(cdt if torch.is_complex(t) else rdt)
+                vals.append(t)
+            else:
+                v = complex(g[f"L{li}_{nm}_scalar"])
+                vals.append(v.real if v.imag == 0 else v)
+        layers.append((float(g[f"L{li}_thickness"]), vals[0], vals[1]))
+    kw = dict(freq=float(g["freq"]), order=[int(v) for v in g["order"]], L=[float(v) for v in g["L"]],
+              layers=layers, dtype=cdt, inc_ang=float(g["inc"]), azi_ang=float(g["azi"]),
+              angle_layer=str(g["angle_layer"]))
+    if bool(g["has_in"]):
+        kw["eps_in"] = float(np.real(g["eps_in"]))
+    if bool(g["has_out"]):
+        kw["eps_out"] = float(np.real(g["eps_out"]))
+    return kw
+
+
+def relerr(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    d = np.linalg.norm((a - b).ravel())
+    s = np.linalg.norm(b.ravel())
+    return d / s if s > 0 else d
