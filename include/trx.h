@@ -1,0 +1,72 @@
+/* libtrx -- C ABI of the MI355X-native RCWA layer-solve hot path.
+ *
+ * The reference (kch3782/torcwa 0.1.4.2) has no FFI of its own: the hot path is a chain of torch.* calls inside
+ * torcwa/rcwa.py and the single-op seam torcwa/torch_eig.py (`Eig.apply`, used at rcwa.py:1236).  This header is
+ * the boundary a maintainer would bind those call sites to (see INTEGRATION.md for the ctypes stub).  Every entry
+ * point cites the reference lines it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / HIP types.  `stream` is a hipStream_t passed as void*.
+ *  - All matrices are row-major, interleaved complex (re,im), layout-identical to torch.complex64 / complex128;
+ *    batched tensors are [batch, rows, cols] contiguous unless a leading dimension / stride is given.
+ *  - All pointers are DEVICE pointers (HBM).  The library never allocates persistent memory, never synchronises
+ *    the host and is stream-ordered and re-entrant: the caller owns every buffer including the workspace, whose
+ *    size is returned by the matching *_ws_bytes() function.
+ *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
+ *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
+ */
+#ifndef TRX_H_
+#define TRX_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TRX_C64 = 0, TRX_C128 = 1 };          /* dtype */
+enum { TRX_OP_N = 0, TRX_OP_T = 1, TRX_OP_C = 2 };
+enum {
+    TRX_OK = 0,
+    TRX_ERR_DTYPE = -1,
+    TRX_ERR_ARG = -2,
+    TRX_ERR_WORKSPACE = -3,
+    TRX_ERR_LAUNCH = -4,
+    TRX_ERR_UNSUPPORTED = -5
+};
+
+int trx_version(void);                        /* major*10000 + minor*100 + patch */
+const char* trx_strerror(int code);
+
+/* ---- Fourier factorisation: torcwa/rcwa.py:1183-1204 (`_material_conv`: fft2 -> Toeplitz gather) --------------
+ * out[b,i,j] = c[b, (m_i-m_j) mod nx, (n_i-n_j) mod ny],  c = DFT2(grid[b]) / (nx*ny),
+ * i = (m+ox)*(2*oy+1) + (n+oy).  Only the (4ox+1)(4oy+1) needed coefficients are computed (pruned DFT).
+ * grid: [batch, nx, ny] real (grid_is_complex=0) or complex, in the real/complex type of `dtype`.
+ * Requires nx > 2*ox and ny > 2*oy (same as the reference's negative-index wrap). */
+size_t trx_convmat_ws_bytes(int dtype, int batch, int nx, int ny, int ox, int oy);
+int trx_convmat(int dtype, int grid_is_complex, const void* grid, int batch, int nx, int ny, int ox, int oy,
+                void* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- dense complex building blocks (the torch.matmul / torch.linalg.inv call sites, rcwa.py:1157-1304) -------- */
+/* C = alpha*op(A)*op(B) + beta*C, batched with element strides; alpha/beta point to HOST complex scalars. */
+int trx_gemm(int dtype, int opA, int opB, int m, int n, int k, const void* alpha, const void* A, int lda,
+             long strideA, const void* B, int ldb, long strideB, const void* beta, void* C, int ldc, long strideC,
+             int batch, void* stream);
+/* Solve A X = B in place (partial-pivot LU; A is overwritten by its factors, B by X).
+ * piv: int[batch*n] device scratch; info: int[batch] device (0 ok, k>0: zero pivot at column k). */
+int trx_lu_solve(int dtype, void* A, int n, void* B, int nrhs, int batch, int* piv, int* info, void* stream);
+/* A <- inverse(A) (LU + solve against the identity); ws: batch*n*n elements. */
+size_t trx_inverse_ws_bytes(int dtype, int n, int batch);
+int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- eigendecomposition: torcwa/torch_eig.py:12-17 (`Eig.forward` -> torch.linalg.eig), rcwa.py:1236/1238 -----
+ * A [batch,n,n] general complex, DESTROYED.  w [batch,n] eigenvalues, V [batch,n,n] right eigenvectors in the
+ * COLUMNS of V (A V = V diag(w)), each column scaled to unit 2-norm (LAPACK geev convention).  Order of the
+ * eigenpairs is unspecified (as in LAPACK).  info[b] = 0 ok, >0: number of eigenvalues that failed to converge. */
+size_t trx_eig_ws_bytes(int dtype, int n, int batch);
+int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
+            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRX_H_ */

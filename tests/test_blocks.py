@@ -1,0 +1,138 @@
+"""Dense building blocks of libtrx (convmat, GEMM, LU solve, inverse) against numpy restatements.
+
+Every test body runs twice: through the CPU kernel-logic emulator (`-m emu`, part of the CPU suite) and on a real
+MI355X through torcwa_amd/libtrx.so (`-m gpu`).  Tolerances: c128 ~1e-11..1e-13 rel, c64 ~1e-5..2e-3 rel (fp32
+round-off of an n~100 LU), stated per test.
+"""
+import numpy as np
+import pytest
+
+from tests.backends import BACKENDS, dtcode, get_backend
+
+RNG = np.random.default_rng(1234)
+
+
+def crand(shape, dtype):
+    return (RNG.standard_normal(shape) + 1j * RNG.standard_normal(shape)).astype(dtype)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 2e-5)])
+@pytest.mark.parametrize("opA,opB", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (2, 2)])
+def test_gemm(backend, dtype, tol, opA, opB):
+    be = get_backend(backend)
+    m, n, k, batch = 70, 67, 37, 2
+    A = crand((batch, m, k) if opA == 0 else (batch, k, m), dtype)
+    B = crand((batch, k, n) if opB == 0 else (batch, n, k), dtype)
+    C0 = crand((batch, m, n), dtype)
+    al, bt = np.array([0.7 - 0.2j], dtype=dtype), np.array([-0.3 + 0.5j], dtype=dtype)
+    dA, dB, dC = be.dev(A), be.dev(B), be.dev(C0)
+    rc = be.lib.gemm(dtcode(dtype), opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
+                     be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
+    assert rc == 0
+    f = {0: lambda x: x, 1: lambda x: x.transpose(0, 2, 1), 2: lambda x: x.conj().transpose(0, 2, 1)}
+    ref = al[0] * (f[opA](A).astype(np.complex128) @ f[opB](B).astype(np.complex128)) + bt[0] * C0
+    assert np.abs(be.host(dC) - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
+@pytest.mark.parametrize("n,nrhs", [(5, 3), (32, 32), (33, 7), (97, 130)])
+def test_lu_solve(backend, dtype, tol, n, nrhs):
+    be = get_backend(backend)
+    batch = 2
+    A = crand((batch, n, n), dtype)
+    A[1, :, 0] *= 1e-3          # force non-trivial pivoting
+    B = crand((batch, n, nrhs), dtype)
+    dA, dB = be.dev(A), be.dev(B)
+    piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+    rc = be.lib.lu_solve(dtcode(dtype), be.ptr(dA), n, be.ptr(dB), nrhs, batch, be.ptr(piv), be.ptr(info), be.stream)
+    assert rc == 0 and (be.host(info) == 0).all()
+    X = np.linalg.solve(A.astype(np.complex128), B.astype(np.complex128))
+    assert np.abs(be.host(dB) - X).max() / np.abs(X).max() < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_lu_singular_info(backend):
+    be = get_backend(backend)
+    n = 40
+    A = crand((1, n, n), np.complex128)
+    A[0, :, 5] = 0.0
+    A[0, 5, :] = 0.0
+    dA, dB = be.dev(A), be.dev(crand((1, n, 2), np.complex128))
+    piv, info = be.empty((1, n), np.int32), be.empty((1,), np.int32)
+    assert be.lib.lu_solve(1, be.ptr(dA), n, be.ptr(dB), 2, 1, be.ptr(piv), be.ptr(info), be.stream) == 0
+    assert be.host(info)[0] > 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
+def test_inverse(backend, dtype, tol):
+    be = get_backend(backend)
+    n, batch = 45, 3
+    A = crand((batch, n, n), dtype)
+    dA = be.dev(A)
+    piv, info = be.empty((batch, n), np.int32), be.empty((batch,), np.int32)
+    nws = be.lib.inverse_ws_bytes(dtcode(dtype), n, batch)
+    ws = be.empty((nws,), np.uint8)
+    assert be.lib.inverse(dtcode(dtype), be.ptr(dA), n, batch, be.ptr(piv), be.ptr(info), be.ptr(ws), nws, be.stream) == 0
+    ref = np.linalg.inv(A.astype(np.complex128))
+    assert np.abs(be.host(dA) - ref).max() / np.abs(ref).max() < tol
+
+
+def _convmat_ref(g, ox, oy):
+    """Independent numpy restatement of torcwa/rcwa.py:1183-1204 (fft2 + negative-index gather)."""
+    nx, ny = g.shape
+    mm, nn = np.meshgrid(np.arange(-ox, ox + 1), np.arange(-oy, oy + 1), indexing="ij")
+    m, n_ = mm.reshape(-1), nn.reshape(-1)
+    c = np.fft.fft2(g.astype(np.complex128)) / (nx * ny)
+    return c[m[:, None] - m[None, :], n_[:, None] - n_[None, :]]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 1e-6)])
+@pytest.mark.parametrize("cplx", [0, 1])
+def test_convmat(backend, dtype, tol, cplx):
+    be = get_backend(backend)
+    batch, nx, ny, ox, oy = 2, 20, 14, 3, 2
+    rdt = np.float64 if dtype == np.complex128 else np.float32
+    g = crand((batch, nx, ny), dtype) if cplx else RNG.standard_normal((batch, nx, ny)).astype(rdt)
+    N = (2 * ox + 1) * (2 * oy + 1)
+    dg, out = be.dev(g), be.empty((batch, N, N), dtype)
+    nws = be.lib.convmat_ws_bytes(dtcode(dtype), batch, nx, ny, ox, oy)
+    ws = be.empty((nws,), np.uint8)
+    assert be.lib.convmat(dtcode(dtype), cplx, be.ptr(dg), batch, nx, ny, ox, oy, be.ptr(out), be.ptr(ws), nws, be.stream) == 0
+    o = be.host(out)
+    for b in range(batch):
+        ref = _convmat_ref(g[b], ox, oy)
+        assert np.abs(o[b] - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_convmat_index_map_is_exact(backend):
+    """A grid made of a single Fourier harmonic (p,q) gives a convolution matrix that is exactly the indicator of
+    m_i-m_j == p, n_i-n_j == q: pins the integer index arithmetic independent of floating point."""
+    be = get_backend(backend)
+    nx, ny, ox, oy = 16, 12, 2, 1
+    x, y = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    for (p, q) in [(1, 0), (0, -1), (-3, 2), (4, -2)]:
+        g = np.exp(2j * np.pi * (p * x / nx + q * y / ny))
+        N = (2 * ox + 1) * (2 * oy + 1)
+        dg, out = be.dev(g[None]), be.empty((1, N, N), np.complex128)
+        nws = be.lib.convmat_ws_bytes(1, 1, nx, ny, ox, oy)
+        ws = be.empty((nws,), np.uint8)
+        assert be.lib.convmat(1, 1, be.ptr(dg), 1, nx, ny, ox, oy, be.ptr(out), be.ptr(ws), nws, be.stream) == 0
+        o = be.host(out)[0]
+        mm, nn = np.meshgrid(np.arange(-ox, ox + 1), np.arange(-oy, oy + 1), indexing="ij")
+        m, n_ = mm.reshape(-1), nn.reshape(-1)
+        expect = ((m[:, None] - m[None, :]) == p) & ((n_[:, None] - n_[None, :]) == q)
+        assert (np.abs(o) > 0.5).tolist() == expect.tolist()
+        assert np.abs(o - expect).max() < 1e-13
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_convmat_rejects_small_grid(backend):
+    be = get_backend(backend)
+    g, out = be.dev(np.zeros((1, 6, 6))), be.empty((1, 49, 49), np.complex128)
+    ws = be.empty((1 << 16,), np.uint8)
+    assert be.lib.convmat(1, 0, be.ptr(g), 1, 6, 6, 3, 3, be.ptr(out), be.ptr(ws), 1 << 16, be.stream) == -2

@@ -1,0 +1,125 @@
+// Shared device/host helpers for libtrx (MI355X / gfx950 RCWA layer-solve kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/trx.h"
+
+#ifndef TRX_DYN_SMEM
+// Dynamic LDS region, 16-byte aligned (cdna_hip_programming.md Guideline 17: no static LDS in front of it).
+#define TRX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#define TRX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel), grid, block, shmem, stream, __VA_ARGS__)
+
+namespace trx {
+
+// ---- interleaved complex (layout == torch.complex64 / complex128) -----------------------------------
+template <class T>
+struct alignas(2 * sizeof(T)) cx {
+    T x, y;
+    __host__ __device__ cx() = default;
+    __host__ __device__ constexpr cx(T re, T im = T(0)) : x(re), y(im) {}
+};
+template <class T> __host__ __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <class T> __host__ __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <class T> __host__ __device__ __forceinline__ cx<T> operator-(cx<T> a) { return {-a.x, -a.y}; }
+template <class T> __host__ __device__ __forceinline__ cx<T> operator*(cx<T> a, cx<T> b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <class T> __host__ __device__ __forceinline__ cx<T> operator*(T s, cx<T> a) { return {s * a.x, s * a.y}; }
+template <class T> __host__ __device__ __forceinline__ cx<T> operator*(cx<T> a, T s) { return {s * a.x, s * a.y}; }
+template <class T> __host__ __device__ __forceinline__ cx<T>& operator+=(cx<T>& a, cx<T> b) { a.x += b.x; a.y += b.y; return a; }
+template <class T> __host__ __device__ __forceinline__ cx<T>& operator-=(cx<T>& a, cx<T> b) { a.x -= b.x; a.y -= b.y; return a; }
+template <class T> __host__ __device__ __forceinline__ cx<T> conj(cx<T> a) { return {a.x, -a.y}; }
+template <class T> __host__ __device__ __forceinline__ T norm2(cx<T> a) { return a.x * a.x + a.y * a.y; }
+template <class T> __host__ __device__ __forceinline__ T abs1(cx<T> a) { return fabs(a.x) + fabs(a.y); }   // LAPACK cabs1
+template <class T> __host__ __device__ __forceinline__ T cabs(cx<T> a) { return hypot(a.x, a.y); }
+// acc += a*b with explicit FMAs (4 real FMAs)
+template <class T> __host__ __device__ __forceinline__ void cfma(cx<T>& acc, cx<T> a, cx<T> b) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += conj(a)*b
+template <class T> __host__ __device__ __forceinline__ void cfma_conj(cx<T>& acc, cx<T> a, cx<T> b) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(-a.y, b.x, acc.y);
+}
+// Smith-style robust complex division a/b
+template <class T> __host__ __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
+    if (fabs(b.x) >= fabs(b.y)) {
+        T r = b.y / b.x, d = b.x + b.y * r;
+        return {(a.x + a.y * r) / d, (a.y - a.x * r) / d};
+    } else {
+        T r = b.x / b.y, d = b.x * r + b.y;
+        return {(a.x * r + a.y) / d, (a.y * r - a.x) / d};
+    }
+}
+template <class T> __host__ __device__ __forceinline__ cx<T> crecip(cx<T> b) { return cdiv(cx<T>(T(1), T(0)), b); }
+// principal square root
+template <class T> __host__ __device__ __forceinline__ cx<T> csqrt(cx<T> z) {
+    T r = hypot(z.x, z.y);
+    if (r == T(0)) return {T(0), T(0)};
+    T u = sqrt(T(0.5) * (r + fabs(z.x)));
+    T v = z.y / (T(2) * u);
+    if (z.x >= T(0)) return {u, v};
+    return {fabs(v), copysign(u, z.y)};
+}
+template <class T> __host__ __device__ __forceinline__ cx<T> cexp(cx<T> z) {
+    T e = exp(z.x), s, c;
+    s = sin(z.y);
+    c = cos(z.y);
+    return {e * c, e * s};
+}
+
+template <class T> struct eps_of;
+template <> struct eps_of<float> { static constexpr float value = 1.1920929e-07f; static constexpr float safmin = 1.17549435e-38f; };
+template <> struct eps_of<double> { static constexpr double value = 2.220446049250313e-16; static constexpr double safmin = 2.2250738585072014e-308; };
+
+// ---- wave / block reductions -------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+
+static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- host-side error helper ---------------------------------------------------------------------------
+#define TRX_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return TRX_ERR_LAUNCH;       \
+    } while (0)
+
+// ---- internal entry points (defined across the .hip files) -------------------------------------------
+struct GemmDesc {            // optional per-batch override (device array), used by the eigensolver
+    long offA, offB, offC;   // element offsets added to the batch base pointers
+    int m, n, k;
+    int pad;
+};
+
+template <class T>
+int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
+         const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch,
+         const GemmDesc* desc = nullptr);
+
+template <class T>
+int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);
+template <class T>
+int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
+             int nrhs, int batch);
+
+}  // namespace trx
