@@ -46,6 +46,9 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp,
     return 0;
 }
 
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+
 namespace hipemu {
 
 extern "C" void hipemu_switch(void** save_sp, void* new_sp);

@@ -1,0 +1,86 @@
+"""trx_eig (batched general complex eigendecomposition) against numpy.linalg.eig.
+
+Eigenpair order/phase is unspecified (as in LAPACK), so the checks are invariants: eigenvalue multiset, residual
+||A V - V diag(w)||, unit column norms, conditioning of V comparable to LAPACK's.  Runs through the CPU emulator
+(`emu`) and on the GPU (`gpu`).
+"""
+import numpy as np
+import pytest
+
+from tests.backends import BACKENDS, dtcode, get_backend
+
+RNG = np.random.default_rng(99)
+
+
+def run_eig(be, A):
+    batch, n, _ = A.shape
+    dtype = A.dtype
+    dA = be.dev(A)
+    w, V = be.empty((batch, n), dtype), be.empty((batch, n, n), dtype)
+    info = be.dev(np.full((batch,), -1, dtype=np.int32))
+    nws = be.lib.eig_ws_bytes(dtcode(dtype), n, batch)
+    ws = be.empty((nws,), np.uint8)
+    rc = be.lib.eig(dtcode(dtype), be.ptr(dA), be.ptr(w), be.ptr(V), n, batch, be.ptr(info), be.ptr(ws), nws, be.stream)
+    assert rc == 0
+    return be.host(w), be.host(V), be.host(info)
+
+
+def match_eigs(w, wref):
+    """max distance after greedy nearest matching (robust to ordering)."""
+    wref = list(wref)
+    worst = 0.0
+    for z in w:
+        j = int(np.argmin([abs(z - r) for r in wref]))
+        worst = max(worst, abs(z - wref[j]))
+        wref.pop(j)
+    return worst
+
+
+def check(A, w, V, info, tol):
+    A128 = A.astype(np.complex128)
+    for b in range(A.shape[0]):
+        assert info[b] == 0
+        scale = np.abs(A128[b]).max() * A.shape[1] ** 0.5
+        res = np.abs(A128[b] @ V[b] - V[b] * w[b][None, :]).max() / scale
+        assert res < tol, res
+        assert np.allclose(np.linalg.norm(V[b], axis=0), 1.0, atol=1e-5 if A.dtype == np.complex64 else 1e-12)
+        wref = np.linalg.eigvals(A128[b])
+        assert match_eigs(w[b], wref) / np.abs(wref).max() < tol * 100
+        assert np.linalg.cond(V[b].astype(np.complex128)) < 1e3 * np.linalg.cond(np.linalg.eig(A128[b])[1])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 5e-6)])
+@pytest.mark.parametrize("n", [3, 5, 33, 40, 70, 101])
+def test_eig_random(backend, dtype, tol, n):
+    if backend == "emu" and n > 70 and dtype == np.complex64:
+        pytest.skip("emulator time budget")
+    be = get_backend(backend)
+    batch = 2
+    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(dtype)
+    A[1] = A[1] + 3.0 * np.diag(np.arange(n)).astype(dtype)      # second matrix: spread spectrum, early deflations
+    w, V, info = run_eig(be, A)
+    check(A, w, V, info, tol)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_degenerate_and_structured(backend):
+    """Exactly repeated eigenvalues (symmetric meta-atoms give degenerate mode pairs), a triangular input, and a
+    block-diagonal input that deflates in the middle."""
+    be = get_backend(backend)
+    n = 24
+    Q, _ = np.linalg.qr(RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)))
+    lam = np.repeat(RNG.standard_normal(n // 2) + 1j * RNG.standard_normal(n // 2), 2)
+    A0 = (Q * lam[None, :]) @ Q.conj().T                       # normal matrix, every eigenvalue double
+    A1 = np.triu(RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)))
+    A2 = np.zeros((n, n), dtype=np.complex128)
+    A2[:10, :10] = RNG.standard_normal((10, 10))
+    A2[10:, 10:] = RNG.standard_normal((14, 14)) + 1j * RNG.standard_normal((14, 14))
+    A = np.stack([A0, A1, A2]).astype(np.complex128)
+    w, V, info = run_eig(be, A)
+    for b in range(3):
+        assert info[b] == 0
+        res = np.abs(A[b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A[b]).max()
+        assert res < 1e-12
+        assert match_eigs(w[b], np.linalg.eigvals(A[b])) < 1e-10
+    assert np.linalg.cond(V[0]) < 1e6        # degenerate pairs must still give independent eigenvectors

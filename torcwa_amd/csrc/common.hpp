@@ -97,6 +97,12 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
 
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Kernels that stage more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in.
+static inline int set_max_dyn_smem(const void* kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+}
+
 // ---- host-side error helper ---------------------------------------------------------------------------
 #define TRX_CHECK_LAUNCH()                                  \
     do {                                                    \

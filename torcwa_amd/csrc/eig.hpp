@@ -1,0 +1,52 @@
+// Internal interfaces of the batched non-Hermitian eigensolver (eig_hess.hip, eig_qr.hip, eig_vec.hip, eig.hip).
+#pragma once
+#include "common.hpp"
+
+namespace trx {
+
+struct EigPlan {
+    static constexpr int HNB = 32;     // Hessenberg panel width
+    static constexpr int QW = 64;      // QR window size (rows/cols staged in LDS)
+    static constexpr int QNS = 16;     // shifts (= bulges) per sweep, spaced 2 rows apart
+    static constexpr int QNMIN = 32;   // active blocks up to this size are finished by the in-LDS single-shift QR
+    static constexpr int VNB = 32;     // block height of the triangular eigenvector back-substitution
+};
+
+// per-matrix iteration state of the QR phase (device resident)
+struct QrState {
+    int ilo, ihi;        // active block (inclusive)
+    int k;               // number of shifts of the running sweep
+    int tau, tau_last;   // global chase step: bulge s sits at p = ilo + tau - 2 s
+    int mode;            // see QR_* below
+    int stall, sweeps;
+    int w0, w1;          // window of the last window step: the pending off-window update acts on [w0, w1)
+    int fail;            // number of unconverged eigenvalues on failure
+    int pad;
+};
+enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4 };
+
+template <class T>
+struct EigBuffers {
+    cx<T>* A;      // [B,n,n] input, becomes H then T
+    cx<T>* Z;      // [B,n,n] accumulated unitary
+    cx<T>* X;      // [B,n,n] triangular eigenvectors
+    cx<T>* Vp;     // [B,n,HNB] panel reflectors (dense, explicit zeros/ones)
+    cx<T>* Yp;     // [B,n,HNB]
+    cx<T>* Tp;     // [B,HNB,HNB]
+    cx<T>* W1;     // [B,HNB*n]
+    cx<T>* W2;     // [B,HNB*n]
+    cx<T>* tau;    // [B,HNB]
+    cx<T>* U;      // [B,QW,QW] window unitary
+    cx<T>* shifts; // [B,QNS]
+    QrState* st;   // [B]
+    int* summary;  // [4]
+};
+
+template <class T> size_t eig_ws_bytes_t(int n, int batch);
+template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, int batch);
+
+template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
+template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
+template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
+
+}  // namespace trx

@@ -1,0 +1,476 @@
+// Batched small-bulge multi-shift QR iteration on upper Hessenberg matrices, H = Z T Z^H (Schur form), with the
+// unitary accumulated into Z.  Second stage of the replacement for torch.linalg.eig (torcwa/torch_eig.py:14).
+//
+// Design for MI355X.  The sequential part of the QR algorithm (generating rotations) only ever touches a narrow
+// diagonal window, so it runs as ONE workgroup per matrix entirely out of LDS (qr_window_kernel: a chain of up to
+// QNS single-shift bulges, 2 rows apart, is chased through a QW x QW window while the window's unitary U is
+// accumulated in LDS).  Everything off the window is updated afterwards with U by wide, embarrassingly parallel
+// slab kernels (apply_left / apply_right) that stream H and Z through LDS once per window step.  Per-matrix
+// progress (active block, shifts, chase position) lives in device memory, so one fixed launch schedule serves the
+// whole batch; matrices that have nothing to do in a step see an empty window and exit.
+//
+//   qr_prepare_kernel  (1 wave / matrix)  deflation scan, active-block bookkeeping, shifts = eigenvalues of the
+//                                         trailing k x k block (in-LDS single-shift QR); blocks <= QNMIN are
+//                                         finished here by the same in-LDS QR with U accumulated.
+//   qr_window_kernel   (256 thr / matrix) one window step of the bulge chain.
+//   apply_left_kernel  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n]
+//   apply_right_kernel H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U
+#include "eig.hpp"
+
+namespace trx {
+namespace {
+
+constexpr int QW = EigPlan::QW, QNS = EigPlan::QNS, QNMIN = EigPlan::QNMIN;
+constexpr int SLD = QNMIN + 1;    // leading dimension of the small in-LDS matrices
+
+template <class T>
+struct Rot {
+    T c;
+    cx<T> s, r;
+};
+
+// G = [[c, s], [-conj(s), c]] with G [f; g] = [r; 0]
+template <class T>
+__device__ __forceinline__ Rot<T> rotg(cx<T> f, cx<T> g) {
+    Rot<T> R;
+    const T ag = cabs(g);
+    if (ag == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
+    const T af = cabs(f);
+    if (af == T(0)) { R.c = T(0); R.s = (T(1) / ag) * conj(g); R.r = cx<T>(ag, T(0)); return R; }
+    const T d = hypot(af, ag);
+    const cx<T> ph = (T(1) / af) * f;
+    R.c = af / d;
+    R.s = (T(1) / d) * (ph * conj(g));
+    R.r = d * ph;
+    return R;
+}
+// rows:  (x, y) <- (c x + s y, -conj(s) x + c y)
+template <class T>
+__device__ __forceinline__ void rot_rows(const Rot<T>& R, cx<T>& x, cx<T>& y) {
+    const cx<T> nx = R.c * x + R.s * y;
+    const cx<T> ny = R.c * y - conj(R.s) * x;
+    x = nx; y = ny;
+}
+// columns (right-multiplication by G^H):  (x, y) <- (c x + conj(s) y, -s x + c y)
+template <class T>
+__device__ __forceinline__ void rot_cols(const Rot<T>& R, cx<T>& x, cx<T>& y) {
+    const cx<T> nx = R.c * x + conj(R.s) * y;
+    const cx<T> ny = R.c * y - R.s * x;
+    x = nx; y = ny;
+}
+
+// Single-shift QR (Wilkinson shift) of an m x m (m <= QNMIN) upper Hessenberg matrix held in LDS, executed by ONE
+// wave (blockDim.x == 64).  On return Hs is upper triangular (Schur form); if Us != nullptr it holds U with
+// H_in = U T U^H.  Returns false if it did not converge.
+template <class T>
+__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us) {
+    const int lane = threadIdx.x;
+    const T ulp = eps_of<T>::value;
+    int ihi = m - 1, its = 0, total = 0;
+    while (ihi > 0) {
+        int l = ihi;
+        while (l > 0) {
+            T s = abs1(Hs[(l - 1) * SLD + l - 1]) + abs1(Hs[l * SLD + l]);
+            if (s == T(0)) s = T(1);
+            if (abs1(Hs[l * SLD + l - 1]) <= ulp * s) break;
+            --l;
+        }
+        __syncthreads();
+        if (l > 0 && lane == 0) Hs[l * SLD + l - 1] = cx<T>(T(0), T(0));
+        __syncthreads();
+        if (l == ihi) { --ihi; its = 0; continue; }
+        ++its; ++total;
+        if (total > 40 * m) return false;
+        cx<T> sig;
+        {
+            const cx<T> a = Hs[(ihi - 1) * SLD + ihi - 1], bq = Hs[(ihi - 1) * SLD + ihi], cq = Hs[ihi * SLD + ihi - 1], d = Hs[ihi * SLD + ihi];
+            if (its % 10 == 0) {
+                sig = d + cx<T>(T(0.75) * fabs(cq.x), T(0));
+            } else {
+                const cx<T> tr = T(0.5) * (a + d);
+                const cx<T> det = (a - tr) * (d - tr) - bq * cq;
+                const cx<T> sq = csqrt(-det);
+                const cx<T> e1 = tr + sq, e2 = tr - sq;
+                sig = (abs1(e1 - d) < abs1(e2 - d)) ? e1 : e2;
+            }
+        }
+        for (int p = l; p < ihi; ++p) {
+            cx<T> f, g;
+            if (p == l) { f = Hs[l * SLD + l] - sig; g = Hs[(l + 1) * SLD + l]; }
+            else { f = Hs[p * SLD + p - 1]; g = Hs[(p + 1) * SLD + p - 1]; }
+            const Rot<T> R = rotg(f, g);
+            __syncthreads();
+            if (lane < 32) {
+                const int lo = (p == l) ? p : p - 1;
+                const int col = lo + lane;
+                if (col < m) {
+                    cx<T> x = Hs[p * SLD + col], y = Hs[(p + 1) * SLD + col];
+                    rot_rows(R, x, y);
+                    if (p != l && col == p - 1) { x = R.r; y = cx<T>(T(0), T(0)); }
+                    Hs[p * SLD + col] = x; Hs[(p + 1) * SLD + col] = y;
+                }
+            } else if (Us) {
+                const int row = lane - 32;
+                if (row < m) {
+                    cx<T> x = Us[row * SLD + p], y = Us[row * SLD + p + 1];
+                    rot_cols(R, x, y);
+                    Us[row * SLD + p] = x; Us[row * SLD + p + 1] = y;
+                }
+            }
+            __syncthreads();
+            if (lane < 32) {
+                const int hi = (p + 2 < ihi) ? p + 2 : ihi;
+                const int row = lane;
+                if (row <= hi) {
+                    cx<T> x = Hs[row * SLD + p], y = Hs[row * SLD + p + 1];
+                    rot_cols(R, x, y);
+                    Hs[row * SLD + p] = x; Hs[row * SLD + p + 1] = y;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    return true;
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void qr_init_kernel(QrState* __restrict__ st, int n) {
+    if (threadIdx.x == 0) {
+        QrState s;
+        s.ilo = 0; s.ihi = n - 1; s.k = 0; s.tau = 0; s.tau_last = -1; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0;
+        s.w0 = 0; s.w1 = 0; s.fail = 0; s.pad = 0;
+        st[blockIdx.x] = s;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ stall_,
+                                                        cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
+                                                        int* __restrict__ summary, int max_sweeps) {
+    __shared__ cx<T> Hs[QNMIN * SLD];
+    __shared__ cx<T> Us[QNMIN * SLD];
+    __shared__ QrState sst;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    cx<T>* H = Aall + (long)b * n * n;
+    if (lane == 0) sst = stall_[b];
+    __syncthreads();
+    QrState st = sst;
+    if (st.mode == QR_DONE) return;
+    const T ulp = eps_of<T>::value;
+    // 1. deflation scan (negligible subdiagonals -> exact zeros)
+    for (int i = 1 + lane; i <= st.ihi; i += 64) {
+        const cx<T> sub = H[(long)i * n + i - 1];
+        if (sub.x != T(0) || sub.y != T(0)) {
+            T s = abs1(H[(long)(i - 1) * n + i - 1]) + abs1(H[(long)i * n + i]);
+            if (s == T(0)) s = T(1);
+            if (abs1(sub) <= ulp * s) H[(long)i * n + i - 1] = cx<T>(T(0), T(0));
+        }
+    }
+    __syncthreads();
+    // 2. new ihi = largest i in [1, ihi] with a non-zero subdiagonal (0 if none)
+    int ihi = 0;
+    for (int base = st.ihi; base >= 1; base -= 64) {
+        const int i = base - lane;
+        int pred = 0;
+        if (i >= 1) { const cx<T> sub = H[(long)i * n + i - 1]; pred = (sub.x != T(0) || sub.y != T(0)); }
+        const unsigned long long mask = __ballot(pred);
+        if (mask) { ihi = base - __builtin_ctzll(mask); break; }
+    }
+    if (ihi <= 0) {
+        if (lane == 0) { st.ihi = 0; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
+        return;
+    }
+    // 3. ilo = largest i in [1, ihi-1] with a zero subdiagonal (0 if none)
+    int ilo = 0;
+    for (int base = ihi - 1; base >= 1; base -= 64) {
+        const int i = base - lane;
+        int pred = 0;
+        if (i >= 1) { const cx<T> sub = H[(long)i * n + i - 1]; pred = (sub.x == T(0) && sub.y == T(0)); }
+        const unsigned long long mask = __ballot(pred);
+        if (mask) { ilo = base - __builtin_ctzll(mask); break; }
+    }
+    if (ihi != st.ihi || ilo != st.ilo) st.stall = 0;
+    st.ihi = ihi; st.ilo = ilo;
+    const int m = ihi - ilo + 1;
+    if (m <= QNMIN) {
+        // finish this block in LDS, publish its unitary for the off-block update
+        for (int e = lane; e < m * m; e += 64) {
+            const int r = e / m, c = e - r * m;
+            Hs[r * SLD + c] = (r <= c + 1) ? H[(long)(ilo + r) * n + ilo + c] : cx<T>(T(0), T(0));
+            Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+        }
+        __syncthreads();
+        const bool ok = small_schur<T>(Hs, m, Us);
+        __syncthreads();
+        cx<T>* U = Uall + (long)b * QW * QW;
+        for (int e = lane; e < m * m; e += 64) {
+            const int r = e / m, c = e - r * m;
+            H[(long)(ilo + r) * n + ilo + c] = (r <= c) ? Hs[r * SLD + c] : cx<T>(T(0), T(0));
+            U[r * QW + c] = Us[r * SLD + c];
+        }
+        if (lane == 0) {
+            st.w0 = ilo; st.w1 = ihi + 1; st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
+            if (!ok) st.fail += m;
+            stall_[b] = st;
+            atomicAdd(&summary[0], 1);
+            atomicOr(&summary[2], 1);
+        }
+        return;
+    }
+    // chase mode: shifts from the trailing k x k block
+    if (st.sweeps >= max_sweeps) {
+        if (lane == 0) { st.fail += ihi + 1; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
+        return;
+    }
+    const int k = (m / 2 < QNS) ? m / 2 : QNS;
+    const int o = ihi - k + 1;
+    for (int e = lane; e < k * k; e += 64) {
+        const int r = e / k, c = e - r * k;
+        Hs[r * SLD + c] = (r <= c + 1) ? H[(long)(o + r) * n + o + c] : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    small_schur<T>(Hs, k, (cx<T>*)nullptr);
+    __syncthreads();
+    cx<T>* sh = shifts_all + (long)b * QNS;
+    if (lane < k) {
+        cx<T> s = Hs[lane * SLD + lane];
+        if (st.stall > 0 && (st.stall % 6) == 0) {
+            const T mag = T(0.75) * cabs(H[(long)ihi * n + ihi - 1]);
+            T sn, cs;
+            const T ang = T(6.283185307179586) * (T)lane / (T)k;
+            sn = sin(ang); cs = cos(ang);
+            s = s + cx<T>(mag * cs, mag * sn);
+        }
+        sh[lane] = s;
+    }
+    if (lane == 0) {
+        st.k = k; st.tau = 0; st.tau_last = (ihi - 1 - ilo) + 2 * (k - 1); st.mode = QR_CHASE;
+        st.stall += 1; st.sweeps += 1; st.w0 = st.w1 = 0;
+        stall_[b] = st;
+        atomicAdd(&summary[0], 1);
+        atomicMax(&summary[1], m);
+    }
+}
+
+// One window step of the bulge chain.
+template <class T>
+__global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ st_all,
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all) {
+    TRX_DYN_SMEM(smem);
+    constexpr int LD = QW + 1;
+    cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
+    cx<T>* Uw = Hw + QW * LD;                          // [QW][LD]
+    Rot<T>* rots = reinterpret_cast<Rot<T>*>(Uw + QW * LD);   // [QNS]   (all LDS lives in the dynamic region)
+    int* rq = reinterpret_cast<int*>(rots + QNS);      // [QNS] window-local position, -1 = inactive
+    int* rfirst = rq + QNS;                            // [QNS]
+    QrState& sst = *reinterpret_cast<QrState*>(rfirst + QNS);
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t == 0) sst = st_all[b];
+    __syncthreads();
+    const QrState st = sst;
+    if (st.mode == QR_SMALL_PENDING) { if (t == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }
+    if (st.mode != QR_CHASE || st.tau > st.tau_last) {
+        if (t == 0 && (st.w0 != 0 || st.w1 != 0)) { st_all[b].w0 = 0; st_all[b].w1 = 0; }
+        return;
+    }
+    cx<T>* H = Aall + (long)b * n * n;
+    const int k = st.k, ilo = st.ilo, ihi = st.ihi;
+    int w0 = ilo + st.tau - 2 * (k - 1) - 1;
+    if (w0 < ilo) w0 = ilo;
+    int w1 = w0 + QW;
+    if (w1 > ihi + 1) w1 = ihi + 1;
+    const int ww = w1 - w0;
+    const int tau_end = (w1 == ihi + 1) ? st.tau_last : (w1 - 3 - ilo);
+    for (int e = t; e < ww * ww; e += 256) {
+        const int r = e / ww, c = e - r * ww;
+        Hw[r * LD + c] = H[(long)(w0 + r) * n + w0 + c];
+        Uw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+    }
+    const cx<T>* sh = shifts_all + (long)b * QNS;
+    __syncthreads();
+    for (int tau = st.tau; tau <= tau_end; ++tau) {
+        if (t < QNS) {
+            int q = -1, first = 0;
+            if (t < k) {
+                const int p = ilo + tau - 2 * t;
+                if (p >= ilo && p <= ihi - 1) {
+                    q = p - w0;
+                    cx<T> f, g;
+                    if (p == ilo) { first = 1; f = Hw[q * LD + q] - sh[t]; g = Hw[(q + 1) * LD + q]; }
+                    else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
+                    rots[t] = rotg(f, g);
+                }
+            }
+            rq[t] = q; rfirst[t] = first;
+        }
+        __syncthreads();
+        // left rotations: rows q, q+1 over the window's columns
+        for (int e = t; e < k * ww; e += 256) {
+            const int s = e / ww, col = e - s * ww;
+            const int q = rq[s];
+            if (q < 0) continue;
+            const int lo = rfirst[s] ? q : q - 1;
+            if (col < lo) continue;
+            cx<T> x = Hw[q * LD + col], y = Hw[(q + 1) * LD + col];
+            rot_rows(rots[s], x, y);
+            if (!rfirst[s] && col == q - 1) { x = rots[s].r; y = cx<T>(T(0), T(0)); }
+            Hw[q * LD + col] = x; Hw[(q + 1) * LD + col] = y;
+        }
+        __syncthreads();
+        // right rotations: columns q, q+1 of the window rows 0..min(q+2, ww-1), and of U (all rows)
+        for (int e = t; e < 2 * k * ww; e += 256) {
+            const int half = e / (k * ww);
+            const int e2 = e - half * k * ww;
+            const int s = e2 / ww, row = e2 - s * ww;
+            const int q = rq[s];
+            if (q < 0) continue;
+            if (half == 0) {
+                const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
+                if (row > hi) continue;
+                cx<T> x = Hw[row * LD + q], y = Hw[row * LD + q + 1];
+                rot_cols(rots[s], x, y);
+                Hw[row * LD + q] = x; Hw[row * LD + q + 1] = y;
+            } else {
+                cx<T> x = Uw[row * LD + q], y = Uw[row * LD + q + 1];
+                rot_cols(rots[s], x, y);
+                Uw[row * LD + q] = x; Uw[row * LD + q + 1] = y;
+            }
+        }
+        __syncthreads();
+    }
+    cx<T>* U = Uall + (long)b * QW * QW;
+    for (int e = t; e < ww * ww; e += 256) {
+        const int r = e / ww, c = e - r * ww;
+        H[(long)(w0 + r) * n + w0 + c] = Hw[r * LD + c];
+        U[r * QW + c] = Uw[r * LD + c];
+    }
+    if (t == 0) { st_all[b].tau = tau_end + 1; st_all[b].w0 = w0; st_all[b].w1 = w1; }
+}
+
+// H[w0:w1, cs:cs+64) <- U^H H[w0:w1, cs:cs+64),  cs = w1 + 64*blockIdx.x
+template <class T>
+__global__ __launch_bounds__(256) void apply_left_kernel(cx<T>* __restrict__ Aall, int n, const QrState* __restrict__ st_all,
+                                                         const cx<T>* __restrict__ Uall) {
+    TRX_DYN_SMEM(smem);
+    constexpr int LD = QW + 1;
+    cx<T>* Us = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
+    cx<T>* Xs = Us + QW * LD;                          // [QW][LD]
+    const int b = blockIdx.y;
+    const int w0 = st_all[b].w0, w1 = st_all[b].w1;
+    const int ww = w1 - w0;
+    const int cs = w1 + 64 * blockIdx.x;
+    if (ww <= 0 || cs >= n) return;
+    const int nc = (n - cs < 64) ? n - cs : 64;
+    cx<T>* H = Aall + (long)b * n * n;
+    const cx<T>* U = Uall + (long)b * QW * QW;
+    const int t = threadIdx.x;
+    for (int e = t; e < ww * ww; e += 256) { const int r = e / ww, c = e - r * ww; Us[r * LD + c] = U[r * QW + c]; }
+    for (int e = t; e < ww * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Xs[r * LD + c] = (c < nc) ? H[(long)(w0 + r) * n + cs + c] : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    const int c = t & 63, rg = t >> 6;
+    cx<T> acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = cx<T>(T(0), T(0));
+    for (int kk = 0; kk < ww; ++kk) {
+        const cx<T> x = Xs[kk * LD + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cfma_conj(acc[i], Us[kk * LD + rg * 16 + i], x);
+    }
+    if (c < nc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = rg * 16 + i;
+            if (r < ww) H[(long)(w0 + r) * n + cs + c] = acc[i];
+        }
+    }
+}
+
+// X[rs:rs+64, w0:w1) <- X[rs:rs+64, w0:w1) U  for X = H (rows < w0; blockIdx.x < nslab) and X = Z (all rows)
+template <class T>
+__global__ __launch_bounds__(256) void apply_right_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n, int nslab,
+                                                          const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall) {
+    TRX_DYN_SMEM(smem);
+    constexpr int LD = QW + 1;
+    cx<T>* Us = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
+    cx<T>* Xs = Us + QW * LD;                          // [64][LD]
+    const int b = blockIdx.y;
+    const int w0 = st_all[b].w0, w1 = st_all[b].w1;
+    const int ww = w1 - w0;
+    if (ww <= 0) return;
+    const bool isZ = (int)blockIdx.x >= nslab;
+    const int rs = 64 * (isZ ? (int)blockIdx.x - nslab : (int)blockIdx.x);
+    const int rend = isZ ? n : w0;
+    if (rs >= rend) return;
+    const int nr = (rend - rs < 64) ? rend - rs : 64;
+    cx<T>* X = (isZ ? Zall : Aall) + (long)b * n * n;
+    const cx<T>* U = Uall + (long)b * QW * QW;
+    const int t = threadIdx.x;
+    for (int e = t; e < ww * ww; e += 256) { const int r = e / ww, c = e - r * ww; Us[r * LD + c] = U[r * QW + c]; }
+    for (int e = t; e < 64 * ww; e += 256) {
+        const int r = e / ww, c = e - r * ww;
+        Xs[r * LD + c] = (r < nr) ? X[(long)(rs + r) * n + w0 + c] : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    const int c = t & 63, rg = t >> 6;
+    if (c >= ww) return;
+    cx<T> acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = cx<T>(T(0), T(0));
+    for (int kk = 0; kk < ww; ++kk) {
+        const cx<T> u = Us[kk * LD + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cfma(acc[i], Xs[(rg * 16 + i) * LD + kk], u);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = rg * 16 + i;
+        if (r < nr) X[(long)(rs + r) * n + w0 + c] = acc[i];
+    }
+}
+
+template <class T>
+__global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __restrict__ info, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) info[b] = st[b].fail;
+}
+
+}  // namespace
+
+template <class T>
+int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info) {
+    constexpr int LD = QW + 1;
+    const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
+    const size_t smw = sm2 + sizeof(Rot<T>) * QNS + sizeof(int) * 2 * QNS + sizeof(QrState);
+    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_left_kernel<T>, sm2) ||
+        set_max_dyn_smem((const void*)apply_right_kernel<T>, sm2))
+        return TRX_ERR_LAUNCH;
+    TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
+    const int max_sweeps = 30 * n + 100;
+    const int nslab = cdiv_i(n, 64);
+    const int adv = QW - 2 * QNS - 1;                 // guaranteed chain advance per window step
+    int summary[4];
+    for (long outer = 0; outer < 64L * n + 1000; ++outer) {
+        if (hipMemsetAsync(B.summary, 0, sizeof(int) * 4, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        TRX_LAUNCH((qr_prepare_kernel<T>), dim3(batch), dim3(64), 0, s, B.A, n, B.st, B.U, B.shifts, B.summary, max_sweeps);
+        if (hipMemcpyAsync(summary, B.summary, sizeof(int) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
+        if (summary[0] == 0) break;
+        const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 1 : 1;
+        for (int q = 0; q < nwin; ++q) {
+            TRX_LAUNCH((qr_window_kernel<T>), dim3(batch), dim3(256), smw, s, B.A, n, B.st, B.U, (const cx<T>*)B.shifts);
+            TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sm2, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U);
+            TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sm2, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U);
+        }
+    }
+    TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template int hessenberg_qr<float>(hipStream_t, const EigBuffers<float>&, int, int, int*);
+template int hessenberg_qr<double>(hipStream_t, const EigBuffers<double>&, int, int, int*);
+
+}  // namespace trx
