@@ -70,13 +70,13 @@ template <class T> __host__ __device__ __forceinline__ cx<T> csqrt(cx<T> z) {
     T u = sqrt(T(0.5) * (r + fabs(z.x)));
     T v = z.y / (T(2) * u);
     if (z.x >= T(0)) return {u, v};
-    return {fabs(v), copysign(u, z.y)};
+    return cx<T>((T)fabs(v), (T)copysign(u, z.y));
 }
 template <class T> __host__ __device__ __forceinline__ cx<T> cexp(cx<T> z) {
     T e = exp(z.x), s, c;
     s = sin(z.y);
     c = cos(z.y);
-    return {e * c, e * s};
+    return cx<T>(e * c, e * s);
 }
 
 template <class T> struct eps_of;
