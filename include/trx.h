@@ -66,6 +66,35 @@ size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
 
+/* ---- layer eigenproblem assembly: torcwa/rcwa.py:1224-1232 (`_eigen_decomposition`, P and Q) -------------------
+ * P = [[Kx Ei Ky, M - Kx Ei Kx],[Ky Ei Ky - M, -Ky Ei Kx]],  Q = [[-Kx Mi Ky, Kx Mi Kx - E],[E - Ky Mi Ky, Ky Mi Kx]]
+ * E, Einv, Mu, Muinv: [batch,N,N] (Einv = inverse of the permittivity convolution matrix, etc.);
+ * kx, ky: [batch,N] complex (the diagonals of Kx_norm, Ky_norm, rcwa.py:1138-1141); P, Q: [batch,2N,2N]. */
+int trx_build_pq(int dtype, const void* E, const void* Einv, const void* Mu, const void* Muinv, const void* kx,
+                 const void* ky, int N, int batch, void* P, void* Q, void* stream);
+
+/* ---- layer scattering matrix: torcwa/rcwa.py:1244-1281 (`_solve_layer_smatrix`) --------------------------------
+ * Inputs  W [batch,n,n] eigenvectors (E_eigvec), n = 2N;
+ *         kzfac [batch,n]: kz (use_q=0: V = P^-1 W diag(kz), rcwa.py:1264) or 1/kz (use_q=1: V = Q W diag(1/kz), :1262);
+ *         vfinv [4,batch,N]: the four diagonals (p11,p12,p21,p22) of Vf^-1 = [[p11,p12],[p21,p22]] (Vf: rcwa.py:1143-1147);
+ *         phase [batch,n] = exp(i*omega*kz*thickness) (rcwa.py:1246).
+ * Outputs S11, S21 [batch,n,n] (the layer's S22 == S11 and S12 == S21 identically), V [batch,n,n] (H_eigvec),
+ *         optional Cplus, Cminus [batch,n,n]: Cf = [Cplus; Cminus], Cb = [Cminus; Cplus] (rcwa.py:1271-1274).
+ * piv: int[3*batch*n], info: int[3*batch] (slot 0..B-1: P factorisation; B..3B-1: the two n x n inverses). */
+size_t trx_layer_smatrix_ws_bytes(int dtype, int N, int batch);
+int trx_layer_smatrix(int dtype, const void* P, const void* Q, const void* W, const void* kzfac, const void* vfinv,
+                      const void* phase, int use_q, int N, int batch, void* S11, void* S21, void* V, void* Cplus,
+                      void* Cminus, int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Redheffer star product: torcwa/rcwa.py:1283-1306 (`_RS_prod`) -----------------------------------------------
+ * Sm, Sn, Sout: HOST arrays of 4 device pointers in the reference's order [S11, S21, S12, S22], each [batch,n,n];
+ * outputs must not alias inputs.  XY [batch,n,2n] x 2 receives X = [t1 Sm11 | t1 Sm12 Sn22] and
+ * Y = [t2 Sn21 Sm11 | t2 Sn22] -- exactly the four products the reference needs to propagate the mode-coupling
+ * coefficients C (rcwa.py:1297-1304), so the caller can do that lazily.  piv: int[batch*n], info: int[batch]. */
+size_t trx_redheffer_ws_bytes(int dtype, int n, int batch);
+int trx_redheffer(int dtype, const void* const* Sm, const void* const* Sn, void* const* Sout, void* XY, int n, int batch,
+                  int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

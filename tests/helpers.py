@@ -51,3 +51,17 @@ def relerr(a, b):
     d = np.linalg.norm((a - b).ravel())
     s = np.linalg.norm(b.ravel())
     return d / s if s > 0 else d
+
+
+def multiset_dist(a, b):
+    """Relative distance between two complex multisets after greedy nearest matching (order-independent; robust to
+    pairs like x+iy / x-iy whose sort order flips on a 1e-16 change of the real part)."""
+    a = np.asarray(a, dtype=np.complex128).ravel()
+    b = list(np.asarray(b, dtype=np.complex128).ravel())
+    assert len(a) == len(b)
+    worst = 0.0
+    for z in a:
+        j = int(np.argmin(np.abs(np.array(b) - z)))
+        worst = max(worst, abs(b[j] - z))
+        b.pop(j)
+    return worst / max(np.abs(a).max(), 1e-300)

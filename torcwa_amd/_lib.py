@@ -25,6 +25,12 @@ _SIGS = {
     "trx_inverse_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_inverse": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_eig_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_build_pq": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "trx_layer_smatrix_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_layer_smatrix": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "trx_redheffer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_redheffer": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_eig": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 

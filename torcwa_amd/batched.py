@@ -1,0 +1,429 @@
+"""Batched RCWA solver: B independent sweep points (frequency / angle / geometry) advance in lock-step.
+
+This is the MI355X-native restatement of the hot path of torcwa.rcwa (kch3782/torcwa 0.1.4.2, torcwa/rcwa.py).  The
+reference is un-batched (one object per sweep point, a Python `for` loop over points, e.g. example/Example1.ipynb
+cell "lamb0 sweep"); here the sweep axis is the leading tensor dimension and every heavy operation is one batched
+libtrx call (include/trx.h).  The drop-in class `torcwa_amd.rcwa` is the B=1 view of this class.
+
+All per-point scalars (`freq`, angles, homogeneous eps/mu, thickness) may be python scalars or [B] tensors.
+"""
+import warnings
+
+import torch
+
+from .engine import Engine, default_engine
+
+# torcwa/rcwa.py:5 -- the reference's pi (typo in the 9th decimal) is part of its observable behaviour
+PI_REF = 3.141592652589793
+
+_DIRS = {"f": "forward", "forward": "forward", "b": "backward", "backward": "backward"}
+_PORTS = {"t": "transmission", "transmission": "transmission", "r": "reflection", "reflection": "reflection"}
+_SBLOCK = {("forward", "transmission"): 0, ("forward", "reflection"): 1, ("backward", "reflection"): 2, ("backward", "transmission"): 3}
+# (numerator side, denominator side) of the power normalisation for S[k]            rcwa.py:377-388
+_KZ_SIDES = {0: ("out", "in"), 1: ("in", "in"), 2: ("out", "out"), 3: ("in", "out")}
+
+
+class BlockDiag2:
+    """2x2 block matrix whose four N x N blocks are diagonal (Vf, Vi, Vo, Sin, Sout all have this form,
+    rcwa.py:1143-1181): stored as four [B,N] diagonals, O(N) algebra instead of dense n^3."""
+
+    def __init__(self, d11, d12, d21, d22):
+        self.d = (d11, d12, d21, d22)
+
+    def __add__(self, o):
+        return BlockDiag2(*[a + b for a, b in zip(self.d, o.d)])
+
+    def __sub__(self, o):
+        return BlockDiag2(*[a - b for a, b in zip(self.d, o.d)])
+
+    def __neg__(self):
+        return BlockDiag2(*[-a for a in self.d])
+
+    def scale(self, s):
+        return BlockDiag2(*[s * a for a in self.d])
+
+    def __matmul__(self, o):
+        a, b, c, d = self.d
+        e, f, g, h = o.d
+        return BlockDiag2(a * e + b * g, a * f + b * h, c * e + d * g, c * f + d * h)
+
+    def inv(self):
+        a, b, c, d = self.d
+        det = a * d - b * c
+        return BlockDiag2(d / det, -b / det, -c / det, a / det)
+
+    def dense(self):
+        a, b, c, d = self.d
+        top = torch.cat((torch.diag_embed(a), torch.diag_embed(b)), dim=2)
+        bot = torch.cat((torch.diag_embed(c), torch.diag_embed(d)), dim=2)
+        return torch.cat((top, bot), dim=1)
+
+
+def _halfspace_V(kx, ky, epsmu):
+    """E->H map of a homogeneous half space, eps*mu = epsmu ([B] or scalar)        rcwa.py:1143-1147"""
+    kz = torch.sqrt(epsmu - kx ** 2 - ky ** 2)
+    kz = torch.where(torch.imag(kz) < 0, torch.conj(kz), kz)
+    return BlockDiag2(-ky * kx / kz, -kz - ky ** 2 / kz, kz + kx ** 2 / kz, kx * ky / kz)
+
+
+class BatchedRCWA:
+    def __init__(self, freq, order, L, *, batch=None, dtype=torch.complex64, device=None, stable_eig_grad=True,
+                 avoid_Pinv_instability=False, max_Pinv_instability=0.005, precision="high", engine=None,
+                 keep_coupling=True):
+        if dtype != torch.complex64 and dtype != torch.complex128:                      # rcwa.py:37-41
+            warnings.warn("Invalid simulation data type. Set as torch.complex64.", UserWarning)
+            dtype = torch.complex64
+        self._dtype = dtype
+        self.engine = engine if engine is not None else (default_engine() if device is None else Engine(device=device))
+        self._device = self.engine.device
+        # precision="high": c64 problems are computed in complex128 internally (the reference's own c64 path is only
+        # ~1e-3 accurate at order 15; the <=1e-5 parity gate needs fp64 in eig and LU).
+        self._cdtype = torch.complex128 if (precision == "high" or dtype == torch.complex128) else torch.complex64
+        self._rdtype = torch.float64 if self._cdtype == torch.complex128 else torch.float32
+        self.stable_eig_grad = bool(stable_eig_grad)
+        self.avoid_Pinv_instability = avoid_Pinv_instability is True
+        self.max_Pinv_instability = max_Pinv_instability if self.avoid_Pinv_instability else None
+        self.Pinv_instability = [] if self.avoid_Pinv_instability else None
+        self.Qinv_instability = [] if self.avoid_Pinv_instability else None
+        self.keep_coupling = keep_coupling
+
+        if batch is None:
+            batch = freq.numel() if (torch.is_tensor(freq) and freq.dim() > 0) else (len(freq) if isinstance(freq, (list, tuple)) else 1)
+        self.B = int(batch)
+        self.freq = self._bvec(freq)                                                    # [B] complex
+        self.omega = (2 * PI_REF) * torch.real(self.freq)                               # rcwa.py:61  [B] real
+        self.order = [int(order[0]), int(order[1])]
+        self.order_x = torch.arange(-self.order[0], self.order[0] + 1, dtype=torch.int64, device=self._device)
+        self.order_y = torch.arange(-self.order[1], self.order[1] + 1, dtype=torch.int64, device=self._device)
+        self.order_N = len(self.order_x) * len(self.order_y)
+        self.L = L
+        self.Gx_norm = 1 / (L[0] * self.freq)                                           # rcwa.py:72
+        self.Gy_norm = 1 / (L[1] * self.freq)
+        one = torch.ones(self.B, dtype=self._cdtype, device=self._device)
+        self.eps_in, self.mu_in, self.eps_out, self.mu_out = one, one.clone(), one.clone(), one.clone()
+        self.has_in = self.has_out = False
+        self.layer_N = 0
+        self.thickness = []
+        self.eps_conv, self.mu_conv = [], []
+        self.P, self.Q = [], []
+        self.kz_norm, self.E_eigvec, self.H_eigvec = [], [], []
+        self.Cplus, self.Cminus = [], []
+        self.layer_S11, self.layer_S21 = [], []
+
+    # ---- helpers -----------------------------------------------------------------------------------------
+    def _bvec(self, v, dtype=None):
+        """python scalar / 0-d / [B] tensor -> [B] tensor of the compute dtype."""
+        dt = dtype if dtype is not None else self._cdtype
+        if torch.is_tensor(v):
+            t = v.to(device=self._device, dtype=dt)
+        else:                      # python scalars / lists: build directly in the target precision (no fp32 detour)
+            t = torch.as_tensor(v, dtype=dt, device=self._device)
+        if t.dim() == 0:
+            t = t.expand(self.B).clone()
+        return t.reshape(self.B)
+
+    @property
+    def n(self):
+        return 2 * self.order_N
+
+    # ---- a2 / a3 -----------------------------------------------------------------------------------------
+    def add_input_layer(self, eps=1., mu=1.):                                           # rcwa.py:95-107
+        self.eps_in, self.mu_in, self.has_in = self._bvec(eps), self._bvec(mu), True
+
+    def add_output_layer(self, eps=1., mu=1.):                                          # rcwa.py:109-121
+        self.eps_out, self.mu_out, self.has_out = self._bvec(eps), self._bvec(mu), True
+
+    def set_incident_angle(self, inc_ang, azi_ang, angle_layer="input"):                # rcwa.py:123-144
+        self.inc_ang, self.azi_ang = self._bvec(inc_ang), self._bvec(azi_ang)
+        if angle_layer in ("i", "in", "input"):
+            self.angle_layer = "input"
+        elif angle_layer in ("o", "out", "output"):
+            self.angle_layer = "output"
+        else:
+            warnings.warn("Invalid angle layer. Set as input layer.", UserWarning)
+            self.angle_layer = "input"
+        self._kvectors()
+
+    def _kvectors(self):                                                                # rcwa.py:1124-1181
+        em = self.eps_in * self.mu_in if self.angle_layer == "input" else self.eps_out * self.mu_out
+        nref = torch.real(torch.sqrt(em))
+        self.kx0_norm = nref * torch.sin(self.inc_ang) * torch.cos(self.azi_ang)
+        self.ky0_norm = nref * torch.sin(self.inc_ang) * torch.sin(self.azi_ang)
+        kx = self.kx0_norm[:, None] + self.order_x[None, :] * self.Gx_norm[:, None]     # [B, 2ox+1]
+        ky = self.ky0_norm[:, None] + self.order_y[None, :] * self.Gy_norm[:, None]     # [B, 2oy+1]
+        self.kx_norm, self.ky_norm = kx, ky
+        self.Kx_norm_dn = kx[:, :, None].expand(-1, -1, ky.shape[1]).reshape(self.B, -1).contiguous()   # x-major
+        self.Ky_norm_dn = ky[:, None, :].expand(-1, kx.shape[1], -1).reshape(self.B, -1).contiguous()
+        kxd, kyd = self.Kx_norm_dn, self.Ky_norm_dn
+        self._Vf = _halfspace_V(kxd, kyd, 1.0)
+        self._Vfinv = self._Vf.inv()
+        self._Sin = self._Sout = None
+        if self.has_in:                                                                 # rcwa.py:1149-1164
+            self._Vi = _halfspace_V(kxd, kyd, (self.eps_in * self.mu_in)[:, None])
+            T = (self._Vf + self._Vi).inv()
+            D = self._Vf - self._Vi
+            self._Sin = [(T @ self._Vi).scale(2), -(T @ D), T @ D, (T @ self._Vf).scale(2)]
+        if self.has_out:                                                                # rcwa.py:1166-1181
+            self._Vo = _halfspace_V(kxd, kyd, (self.eps_out * self.mu_out)[:, None])
+            T = (self._Vf + self._Vo).inv()
+            D = self._Vf - self._Vo
+            self._Sout = [(T @ self._Vf).scale(2), T @ D, -(T @ D), (T @ self._Vo).scale(2)]
+
+    # ---- a4-a8 -------------------------------------------------------------------------------------------
+    def add_layer(self, thickness, eps=1., mu=1.):                                      # rcwa.py:146-170
+        eng, N, B, cdt = self.engine, self.order_N, self.B, self._cdtype
+        eps_h, mu_h = self._is_homogeneous(eps), self._is_homogeneous(mu)
+        eye = torch.eye(N, dtype=cdt, device=self._device)
+
+        def conv(v, homog):
+            if homog:
+                s = self._bvec(v)
+                return s[:, None, None] * eye, (1 / s)[:, None, None] * eye, s
+            g = torch.as_tensor(v, device=self._device)
+            if g.dim() == 2:
+                g = g[None].expand(B, -1, -1)
+            C = eng.convmat(g.contiguous(), self.order[0], self.order[1], cdt)          # rcwa.py:1183-1204
+            return C, None, None
+
+        E, Einv, eps_s = conv(eps, eps_h)
+        M, Minv, mu_s = conv(mu, mu_h)
+        self.eps_conv.append(E)
+        self.mu_conv.append(M)
+        self.layer_N += 1
+        d = self._bvec(thickness, self._rdtype)
+        self.thickness.append(d)
+        kxd, kyd = self.Kx_norm_dn, self.Ky_norm_dn
+        if eps_h and mu_h:                                                              # rcwa.py:1206-1222
+            P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
+            W = torch.eye(2 * N, dtype=cdt, device=self._device).expand(B, -1, -1).contiguous()
+            kz = torch.sqrt((eps_s * mu_s)[:, None] - kxd ** 2 - kyd ** 2)
+            kz = torch.where(torch.imag(kz) < 0, torch.conj(kz), kz)
+            kz = torch.cat((kz, kz), dim=1)
+        else:                                                                           # rcwa.py:1224-1242
+            if Einv is None:
+                Einv = eng.inverse(E)
+            if Minv is None:
+                Minv = eng.inverse(M)
+            P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
+            A = eng.gemm(P, Q)
+            lam, W = eng.eig(A, destroy=True)                                           # torch_eig.py:14
+            del A
+            kz = torch.sqrt(lam)
+            kz = torch.where(torch.imag(kz) < 0, -kz, kz)                               # rcwa.py:1241
+        self.P.append(P)
+        self.Q.append(Q)
+        self.kz_norm.append(kz)
+        self.E_eigvec.append(W)
+        self._solve_layer_smatrix()
+
+    def _is_homogeneous(self, v):
+        if isinstance(v, (float, complex)):
+            return True
+        if isinstance(v, int):                     # the reference raises AttributeError here (rcwa.py:156)
+            raise AttributeError("'int' object has no attribute 'dim'")
+        t = torch.as_tensor(v)
+        return t.dim() == 0 or t.dim() == 1
+
+    def _solve_layer_smatrix(self):                                                     # rcwa.py:1244-1281
+        eng = self.engine
+        P, Q, W, kz, d = self.P[-1], self.Q[-1], self.E_eigvec[-1], self.kz_norm[-1], self.thickness[-1]
+        phase = torch.exp(1j * (self.omega * d)[:, None] * kz)                          # rcwa.py:1246
+        vfinv = torch.stack(self._Vfinv.d, dim=0).to(self._cdtype).contiguous()         # [4,B,N]
+        if not self.avoid_Pinv_instability:
+            S11, S21, V, cp, cm = eng.layer_smatrix(P, None, W, kz, vfinv, phase, use_q=False, want_c=self.keep_coupling)
+        else:                                                                           # rcwa.py:1249-1262
+            n = self.n
+            I = torch.eye(n, dtype=self._cdtype, device=self._device)
+            Pinv = eng.inverse(P)
+            ins1 = torch.amax(torch.abs(eng.gemm(P, Pinv) - I), dim=(1, 2))
+            ins2 = torch.amax(torch.abs(eng.gemm(Pinv, P) - I), dim=(1, 2))
+            qins = torch.amax(torch.abs(eng.gemm(Q, eng.inverse(Q)) - I), dim=(1, 2))   # computed twice in the reference
+            self.Pinv_instability.append(torch.maximum(ins1, ins2))
+            self.Qinv_instability.append(qins)
+            bad = self.Pinv_instability[-1] >= self.max_Pinv_instability
+            S11, S21, V, cp, cm = eng.layer_smatrix(P, None, W, kz, vfinv, phase, use_q=False, want_c=self.keep_coupling)
+            if bool(bad.any()):
+                alt = eng.layer_smatrix(None, Q, W, 1 / kz, vfinv, phase, use_q=True, want_c=self.keep_coupling)
+                sel = bad[:, None, None]
+                S11, S21, V = torch.where(sel, alt[0], S11), torch.where(sel, alt[1], S21), torch.where(sel, alt[2], V)
+                if self.keep_coupling:
+                    cp, cm = torch.where(sel, alt[3], cp), torch.where(sel, alt[4], cm)
+        self.H_eigvec.append(V)
+        self.layer_S11.append(S11)
+        self.layer_S21.append(S21)
+        self.Cplus.append(cp)
+        self.Cminus.append(cm)
+
+    # ---- a9 / a10 ----------------------------------------------------------------------------------------
+    def _RS_prod(self, Sm, Sn, Cm, Cn):                                                 # rcwa.py:1283-1306
+        eng = self.engine
+        S, X1, X2, Y1, Y2 = eng.redheffer(Sm, Sn)
+        C = [[], []]
+        for m in range(len(Cm[0])):
+            C[0].append(Cm[0][m] + eng.gemm(Cm[1][m], Y1.contiguous()))
+            C[1].append(eng.gemm(Cm[1][m], Y2.contiguous()))
+        for k in range(len(Cn[0])):
+            C[0].append(eng.gemm(Cn[0][k], X1.contiguous()))
+            C[1].append(Cn[1][k] + eng.gemm(Cn[0][k], X2.contiguous()))
+        return S, C
+
+    def _layer_S(self, i):
+        # the layer S-matrix is symmetric under port exchange: S22 = S11, S12 = S21
+        return [self.layer_S11[i], self.layer_S21[i], self.layer_S21[i], self.layer_S11[i]]
+
+    def _layer_C(self, i):
+        if not self.keep_coupling:
+            return [[], []]
+        return [[torch.cat((self.Cplus[i], self.Cminus[i]), dim=1)], [torch.cat((self.Cminus[i], self.Cplus[i]), dim=1)]]
+
+    def solve_global_smatrix(self):                                                     # rcwa.py:173-211
+        n, B = self.n, self.B
+        self._zero_layer_S = False
+        if self.layer_N > 0:
+            S = self._layer_S(0)
+            C = self._layer_C(0)
+        else:
+            I = torch.eye(n, dtype=self._cdtype, device=self._device).expand(B, -1, -1).contiguous()
+            Z = torch.zeros((B, n, n), dtype=self._cdtype, device=self._device)
+            S = [I, Z, Z.clone(), I.clone()]
+            C = [[], []]
+            self._zero_layer_S = not (self.has_in or self.has_out)     # reference stores 1-D zeros (rcwa.py:187-188)
+        for i in range(1, self.layer_N):
+            S, C = self._RS_prod(S, self._layer_S(i), C, self._layer_C(i))
+        if self.has_in:
+            S, C = self._RS_prod([b.dense() for b in self._Sin], S, [[], []], C)
+        if self.has_out:
+            S, C = self._RS_prod(S, [b.dense() for b in self._Sout], C, [[], []])
+        self.S = S
+        self.C = C
+
+    # ---- a11 ---------------------------------------------------------------------------------------------
+    def _matching_indices(self, orders):                                                # rcwa.py:1115-1122
+        ox, oy = self.order
+        orders[orders[:, 0] < -ox, 0] = -ox
+        orders[orders[:, 0] > ox, 0] = ox
+        orders[orders[:, 1] < -oy, 1] = -oy
+        orders[orders[:, 1] > oy, 1] = oy
+        return len(self.order_y) * (orders[:, 0] + ox) + orders[:, 1] + oy
+
+    def _kz_real(self, side, evan, abs_when_evanescent=False):
+        em = self.eps_in * self.mu_in if side == "in" else self.eps_out * self.mu_out
+        kzc = torch.sqrt(em[:, None] - self.Kx_norm_dn ** 2 - self.Ky_norm_dn ** 2)
+        ev = torch.abs(torch.real(kzc) / torch.imag(kzc)) < evan
+        repl = torch.abs(torch.real(kzc)) if abs_when_evanescent else torch.zeros_like(torch.real(kzc))
+        kz = torch.where(ev, repl, torch.real(kzc))
+        return torch.cat((kz, kz), dim=1)                                               # [B, n]
+
+    def S_parameters(self, orders, *, direction="forward", port="transmission", polarization="xx", ref_order=[0, 0],
+                     power_norm=True, evanscent=1e-3):                                  # rcwa.py:300-524
+        dev = self._device
+        orders = torch.as_tensor(orders, dtype=torch.int64, device=dev).reshape([-1, 2])
+        if direction in _DIRS:
+            direction = _DIRS[direction]
+        else:
+            warnings.warn("Invalid propagation direction. Set as forward.", UserWarning)
+            direction = "forward"
+        if port in _PORTS:
+            port = _PORTS[port]
+        else:
+            warnings.warn("Invalid port. Set as tramsmission.", UserWarning)
+            port = "transmission"
+        if polarization not in ("xx", "yx", "xy", "yy", "pp", "sp", "ps", "ss"):
+            warnings.warn("Invalid polarization. Set as xx.", UserWarning)
+            polarization = "xx"
+        ref_order = torch.as_tensor(ref_order, dtype=torch.int64, device=dev).reshape([1, 2])
+        oi = self._matching_indices(orders)
+        ri = self._matching_indices(ref_order)
+        N = self.order_N
+        k = _SBLOCK[(direction, port)]
+        Sk = self.S[k]
+        num_side, den_side = _KZ_SIDES[k]
+
+        if polarization in ("xx", "yx", "xy", "yy"):
+            if polarization[0] == "y":
+                oi = oi + N
+            if polarization[1] == "y":
+                ri = ri + N
+            val = Sk[:, oi, ri[0]]                                                       # [B, M]
+            if power_norm:
+                kzn, kzd = self._kz_real(num_side, evanscent), self._kz_real(den_side, evanscent)
+                kxr = torch.cat((torch.real(self.Kx_norm_dn),) * 2, dim=1)
+                kyr = torch.cat((torch.real(self.Ky_norm_dn),) * 2, dim=1)
+                pn = kxr if polarization[0] == "x" else kyr                              # rcwa.py:368-375
+                pd = kxr if polarization[1] == "x" else kyr
+                norm = torch.sqrt((1 + (pn[:, oi] / kzn[:, oi]) ** 2) / (1 + (pd[:, ri] / kzd[:, ri]) ** 2))
+                norm = norm * torch.sqrt(kzn[:, oi] / kzd[:, ri])
+                val = val * norm
+            val = torch.where(torch.isinf(val), torch.zeros_like(val), val)
+            val = torch.where(torch.isnan(val), torch.zeros_like(val), val)
+            return val.to(self._dtype)
+
+        # ps basis                                                                         rcwa.py:410-521
+        osign, rsign = {0: (1, 1), 1: (-1, 1), 2: (1, -1), 3: (-1, -1)}[k]
+        em_in, em_out = self.eps_in * self.mu_in, self.eps_out * self.mu_out
+        ok2 = {0: em_out, 1: em_in, 2: em_out, 3: em_in}[k]
+        rk2 = {0: em_in, 1: em_in, 2: em_out, 3: em_out}[k]
+
+        def angles(idx, k2, sign):
+            kx_, ky_ = self.Kx_norm_dn[:, idx], self.Ky_norm_dn[:, idx]
+            kt = torch.sqrt(kx_ ** 2 + ky_ ** 2)
+            kzc = torch.sqrt(k2[:, None] - kx_ ** 2 - ky_ ** 2)
+            kzs = sign * torch.abs(torch.real(kzc))
+            ev = torch.abs(torch.real(kzc) / torch.imag(kzc)) < evanscent
+            return torch.atan2(torch.real(kt), kzs), torch.atan2(torch.real(ky_), torch.real(kx_)), ev
+
+        o_inc, o_azi, o_ev = angles(oi, ok2, osign)
+        r_inc, r_azi, r_ev = angles(ri, rk2, rsign)
+        r0 = int(ri[0])
+        xx, xy = Sk[:, oi, r0], Sk[:, oi, r0 + N]
+        yx, yy = Sk[:, oi + N, r0], Sk[:, oi + N, r0 + N]
+        zero = torch.zeros_like(xx)
+        xx, xy, yx, yy = (torch.where(o_ev, zero, t) for t in (xx, xy, yx, yy))
+        co, so, ci = torch.cos(o_azi), torch.sin(o_azi), torch.cos(o_inc)
+        cr, sr, cri = torch.cos(r_azi), torch.sin(r_azi), torch.cos(r_inc)
+        if polarization == "pp":
+            val = co / ci * cri * cr * xx + so / ci * cri * cr * yx + co / ci * cri * sr * xy + so / ci * cri * sr * yy
+        elif polarization == "ps":
+            val = co / ci * (-1) * sr * xx + so / ci * (-1) * sr * yx + co / ci * cr * xy + so / ci * cr * yy
+        elif polarization == "sp":
+            val = -so * cri * cr * xx + co * cri * cr * yx + -so * cri * sr * xy + co * cri * sr * yy
+        else:
+            val = -so * (-1) * sr * xx + co * (-1) * sr * yx + -so * cr * xy + co * cr * yy
+        val = torch.where(torch.isinf(val), torch.zeros_like(val), val)
+        val = torch.where(torch.isnan(val), torch.zeros_like(val), val)
+        if power_norm:
+            kz_in = self._kz_real("in", evanscent)
+            kz_out = self._kz_real("out", evanscent, abs_when_evanescent=True)          # rcwa.py:495
+            kzn = kz_out if num_side == "out" else kz_in
+            kzd = kz_out if den_side == "out" else kz_in
+            val = val * torch.sqrt(kzn[:, oi] / kzd[:, ri])
+        val = torch.where(r_ev, torch.zeros_like(val), val)                             # rcwa.py:462-464 (per point)
+        return val.to(self._dtype)
+
+    def diffraction_angle(self, orders, *, layer="output", unit="radian"):               # rcwa.py:214-262
+        orders = torch.as_tensor(orders, dtype=torch.int64, device=self._device).reshape([-1, 2])
+        if layer in ("i", "in", "input"):
+            layer = "input"
+        elif layer in ("o", "out", "output"):
+            layer = "output"
+        else:
+            warnings.warn("Invalid layer. Set as output layer.", UserWarning)
+            layer = "output"
+        if unit in ("r", "rad", "radian"):
+            unit = "radian"
+        elif unit in ("d", "deg", "degree"):
+            unit = "degree"
+        else:
+            warnings.warn("Invalid unit. Set as radian.", UserWarning)
+            unit = "radian"
+        idx = self._matching_indices(orders)
+        eps = self.eps_in if layer == "input" else self.eps_out
+        mu = self.mu_in if layer == "input" else self.mu_out
+        kx, ky = self.Kx_norm_dn[:, idx], self.Ky_norm_dn[:, idx]
+        kt = torch.sqrt(kx ** 2 + ky ** 2)
+        kz = torch.sqrt((eps * mu)[:, None] - kx ** 2 - ky ** 2)
+        inc = torch.atan2(torch.real(kt), torch.real(kz))
+        azi = torch.atan2(torch.real(ky), torch.real(kx))
+        if unit == "degree":
+            inc, azi = (180. / PI_REF) * inc, (180. / PI_REF) * azi
+        return inc, azi

@@ -1,0 +1,251 @@
+// Layer eigenproblem assembly, layer scattering matrix and Redheffer star product (batched, row-major complex).
+// Replaces torcwa/rcwa.py:1224-1232 (`_eigen_decomposition`: P, Q), :1244-1281 (`_solve_layer_smatrix`) and
+// :1283-1306 (`_RS_prod`) with the lean formulation of SURVEY.md section 7.2, which is algebraically identical:
+//
+//   * Kx, Ky, Kz, X=exp(i w kz d), Vf are (block-)diagonal: they are never materialised, every product with them
+//     is a fused row/column scaling inside an assembly kernel.
+//   * [[A,B],[B,A]]^-1 of rcwa.py:1268-1274 (a 2n x 2n inverse, evaluated twice) is replaced by two n x n
+//     inverses:  c+ + c- = 2 (A+B)^-1,  c+ - c- = 2 (A-B)^-1,  and S22 = S11, S12 = S21, Cb = swap(Cf).
+//   * The star product needs ONE LU (push-through identity (I-BA)^-1 B = B (I-AB)^-1) instead of two inverses.
+#include "common.hpp"
+
+namespace trx {
+namespace {
+
+// P = [[Kx Ei Ky, M - Kx Ei Kx], [Ky Ei Ky - M, -Ky Ei Kx]],  Q = [[-Kx Mi Ky, Kx Mi Kx - E], [E - Ky Mi Ky, Ky Mi Kx]]
+template <class T>
+__global__ __launch_bounds__(256) void build_pq_kernel(const cx<T>* __restrict__ E, const cx<T>* __restrict__ Ei,
+                                                       const cx<T>* __restrict__ M, const cx<T>* __restrict__ Mi,
+                                                       const cx<T>* __restrict__ kx, const cx<T>* __restrict__ ky, int N,
+                                                       cx<T>* __restrict__ P, cx<T>* __restrict__ Q) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const long o = ((long)b * N + i) * N + j;
+    const cx<T> e = E[o], ei = Ei[o], m = M[o], mi = Mi[o];
+    const cx<T> kxi = kx[(long)b * N + i], kyi = ky[(long)b * N + i], kxj = kx[(long)b * N + j], kyj = ky[(long)b * N + j];
+    const int n = 2 * N;
+    cx<T>* Pb = P + (long)b * n * n;
+    cx<T>* Qb = Q + (long)b * n * n;
+    const long r0 = (long)i * n + j, r1 = (long)(i + N) * n + j;
+    Pb[r0] = kxi * ei * kyj;
+    Pb[r0 + N] = m - kxi * ei * kxj;
+    Pb[r1] = kyi * ei * kyj - m;
+    Pb[r1 + N] = -(kyi * ei * kxj);
+    Qb[r0] = -(kxi * mi * kyj);
+    Qb[r0 + N] = kxi * mi * kxj - e;
+    Qb[r1] = e - kyi * mi * kyj;
+    Qb[r1 + N] = kyi * mi * kxj;
+}
+
+// out[i,j] = in[i,j] * s[j]
+template <class T>
+__global__ __launch_bounds__(256) void scale_cols_kernel(const cx<T>* __restrict__ in, const cx<T>* __restrict__ s, int n, cx<T>* __restrict__ out) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long o = ((long)b * n + i) * n + j;
+    out[o] = in[o] * s[(long)b * n + j];
+}
+
+// F = Vf^-1 V (Vf^-1 2x2-block-diagonal, rows i and i+N coupled);  Tp = (W+F) + (W-F) X,  Tm = (W+F) - (W-F) X
+template <class T>
+__global__ __launch_bounds__(256) void layer_T_kernel(const cx<T>* __restrict__ W, const cx<T>* __restrict__ V,
+                                                      const cx<T>* __restrict__ p11, const cx<T>* __restrict__ p12,
+                                                      const cx<T>* __restrict__ p21, const cx<T>* __restrict__ p22,
+                                                      const cx<T>* __restrict__ x, int N, cx<T>* __restrict__ Tp, cx<T>* __restrict__ Tm) {
+    const int b = blockIdx.z, i = blockIdx.y;           // i in [0, N)
+    const int n = 2 * N;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long o0 = ((long)b * n + i) * n + j, o1 = ((long)b * n + i + N) * n + j;
+    const cx<T> v0 = V[o0], v1 = V[o1], w0 = W[o0], w1 = W[o1];
+    const long d = (long)b * N + i;
+    const cx<T> f0 = p11[d] * v0 + p12[d] * v1;
+    const cx<T> f1 = p21[d] * v0 + p22[d] * v1;
+    const cx<T> xj = x[(long)b * n + j];
+    const cx<T> a0 = w0 + f0, b0 = (w0 - f0) * xj;
+    const cx<T> a1 = w1 + f1, b1 = (w1 - f1) * xj;
+    Tp[o0] = a0 + b0; Tm[o0] = a0 - b0;
+    Tp[o1] = a1 + b1; Tm[o1] = a1 - b1;
+}
+
+// G1 = (I+X) Tip, G2 = (I-X) Tim (row scalings);  optionally c+ = Tip + Tim, c- = Tip - Tim
+template <class T>
+__global__ __launch_bounds__(256) void layer_G_kernel(const cx<T>* __restrict__ Tip, const cx<T>* __restrict__ Tim, const cx<T>* __restrict__ x,
+                                                      int n, cx<T>* __restrict__ G1, cx<T>* __restrict__ G2, cx<T>* __restrict__ cp, cx<T>* __restrict__ cm) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long o = ((long)b * n + i) * n + j;
+    const cx<T> xi = x[(long)b * n + i];
+    const cx<T> tp = Tip[o], tm = Tim[o];
+    const cx<T> one(T(1), T(0));
+    if (cp) { cp[o] = tp + tm; cm[o] = tp - tm; }
+    G1[o] = (one + xi) * tp;
+    G2[o] = (one - xi) * tm;
+}
+
+// S11 = Mp - Mm,  S21 = Mp + Mm - I
+template <class T>
+__global__ __launch_bounds__(256) void layer_S_kernel(const cx<T>* __restrict__ Mp, const cx<T>* __restrict__ Mm, int n, cx<T>* __restrict__ S11, cx<T>* __restrict__ S21) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long o = ((long)b * n + i) * n + j;
+    const cx<T> p = Mp[o], m = Mm[o];
+    S11[o] = p - m;
+    cx<T> s = p + m;
+    if (i == j) s.x -= T(1);
+    S21[o] = s;
+}
+
+// dst[b, i, dcol0 + j] = (identity ? delta_ij : 0) + alpha * src[b, i, j]    (strided block copy / init)
+template <class T>
+__global__ __launch_bounds__(256) void block_copy_kernel(const cx<T>* __restrict__ src, int lds, long ss, cx<T>* __restrict__ dst, int ldd, long sd,
+                                                         int rows, int cols, T alpha, int add_identity) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols || i >= rows) return;
+    cx<T> v(T(0), T(0));
+    if (src) v = alpha * src[(long)b * ss + (long)i * lds + j];
+    if (add_identity && i == j) v.x += T(1);
+    dst[(long)b * sd + (long)i * ldd + j] = v;
+}
+
+template <class T>
+int build_pq_t(hipStream_t s, const void* E, const void* Ei, const void* M, const void* Mi, const void* kx, const void* ky, int N, int batch, void* P, void* Q) {
+    TRX_LAUNCH((build_pq_kernel<T>), dim3(cdiv_i(N, 256), N, batch), dim3(256), 0, s, (const cx<T>*)E, (const cx<T>*)Ei, (const cx<T>*)M, (const cx<T>*)Mi,
+               (const cx<T>*)kx, (const cx<T>*)ky, N, (cx<T>*)P, (cx<T>*)Q);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template <class T>
+int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* W, const cx<T>* kz, const cx<T>* pv, const cx<T>* x, int use_q,
+                    int N, int batch, cx<T>* S11, cx<T>* S21, cx<T>* V, cx<T>* cp, cx<T>* cm, int* piv, int* info, cx<T>* ws) {
+    const int n = 2 * N;
+    const long nn = (long)n * n, bn = (long)batch * nn;
+    const cx<T> one(T(1), T(0)), zero(T(0), T(0));
+    const dim3 g(cdiv_i(n, 256), n, batch), blk(256);
+    cx<T>* T2 = ws;              // [2B, n, n]: Tp | Tm, inverted in place
+    cx<T>* G = ws + 2 * bn;      // [2B, n, n]: scratch (LU copy of P / inverse workspace / G1 | G2)
+    cx<T>* Mx = ws + 4 * bn;     // [2B, n, n]: Mp | Mm
+    int rc;
+    if (!use_q) {
+        // V = P^-1 (W Kz)                                                       (rcwa.py:1248, 1264)
+        if (hipMemcpyAsync(G, P, sizeof(cx<T>) * bn, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        TRX_LAUNCH((scale_cols_kernel<T>), g, blk, 0, s, W, kz, n, V);
+        rc = lu_factor<T>(s, G, n, nn, n, piv, batch, info); if (rc) return rc;
+        rc = lu_solve<T>(s, G, n, nn, n, piv, V, n, nn, n, batch); if (rc) return rc;
+    } else {
+        // V = Q W Kz^-1   (kz holds 1/kz on this path)                         (rcwa.py:1262)
+        TRX_LAUNCH((scale_cols_kernel<T>), g, blk, 0, s, W, kz, n, G);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Q, n, nn, G, n, nn, zero, V, n, nn, batch); if (rc) return rc;
+        if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    }
+    const long bN = (long)batch * N;
+    TRX_LAUNCH((layer_T_kernel<T>), dim3(cdiv_i(n, 256), N, batch), blk, 0, s, W, (const cx<T>*)V, pv, pv + bN, pv + 2 * bN, pv + 3 * bN, x, N, T2, T2 + bn);
+    // invert Tp and Tm as one batch of 2B
+    {
+        int* piv2 = piv + (long)batch * n;           // caller provides 3*batch*n ints
+        int* info2 = info + batch;                   // and 3*batch info slots
+        rc = lu_factor<T>(s, T2, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
+        TRX_LAUNCH((block_copy_kernel<T>), dim3(cdiv_i(n, 256), n, 2 * batch), blk, 0, s, (const cx<T>*)nullptr, n, nn, G, n, nn, n, n, T(0), 1);
+        rc = lu_solve<T>(s, T2, n, nn, n, piv2, G, n, nn, n, 2 * batch); if (rc) return rc;
+    }
+    // G now holds Tip | Tim; form G1 | G2 into T2 (factors no longer needed)
+    TRX_LAUNCH((layer_G_kernel<T>), g, blk, 0, s, (const cx<T>*)G, (const cx<T>*)(G + bn), x, n, T2, T2 + bn, cp, cm);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, W, n, nn, T2, n, nn, zero, Mx, n, nn, batch); if (rc) return rc;
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, W, n, nn, T2 + bn, n, nn, zero, Mx + bn, n, nn, batch); if (rc) return rc;
+    TRX_LAUNCH((layer_S_kernel<T>), g, blk, 0, s, (const cx<T>*)Mx, (const cx<T>*)(Mx + bn), n, S11, S21);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template <class T>
+int redheffer_t(hipStream_t s, const cx<T>* const* Sm, const cx<T>* const* Sn, cx<T>* const* O, cx<T>* XY, int n, int batch, int* piv, int* info, cx<T>* ws) {
+    // index convention of the reference: [0]=S11, [1]=S21, [2]=S12, [3]=S22            (rcwa.py:1284)
+    const long nn = (long)n * n, bn = (long)batch * nn;
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0)), zero(T(0), T(0));
+    const dim3 g(cdiv_i(n, 256), n, batch), blk(256);
+    cx<T>* K = ws;                 // [B,n,n]
+    cx<T>* X = XY;                 // [B,n,2n]  X1 | X2
+    cx<T>* Y = XY + 2 * bn;        // [B,n,2n]  Y1 | Y2
+    int rc;
+    // K = I - Sm12 Sn21
+    TRX_LAUNCH((block_copy_kernel<T>), g, blk, 0, s, (const cx<T>*)nullptr, n, nn, K, n, nn, n, n, T(0), 1);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, mone, Sm[2], n, nn, Sn[1], n, nn, one, K, n, nn, batch); if (rc) return rc;
+    // RHS = [Sm11 | Sm12 Sn22]
+    TRX_LAUNCH((block_copy_kernel<T>), g, blk, 0, s, Sm[0], n, nn, X, 2 * n, 2 * nn, n, n, T(1), 0);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sm[2], n, nn, Sn[3], n, nn, zero, X + n, 2 * n, 2 * nn, batch); if (rc) return rc;
+    rc = lu_factor<T>(s, K, n, nn, n, piv, batch, info); if (rc) return rc;
+    rc = lu_solve<T>(s, K, n, nn, n, piv, X, 2 * n, 2 * nn, 2 * n, batch); if (rc) return rc;
+    // S11 = Sn11 X1 ; S12 = Sn12 + Sn11 X2
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sn[0], n, nn, X, 2 * n, 2 * nn, zero, O[0], n, nn, batch); if (rc) return rc;
+    TRX_LAUNCH((block_copy_kernel<T>), g, blk, 0, s, Sn[2], n, nn, O[2], n, nn, n, n, T(1), 0);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sn[0], n, nn, X + n, 2 * n, 2 * nn, one, O[2], n, nn, batch); if (rc) return rc;
+    // Y1 = Sn21 X1 ; Y2 = Sn22 + Sn21 X2       (= t2 Sn21 Sm11 and t2 Sn22 of rcwa.py:1292-1294, 1299-1300)
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sn[1], n, nn, X, 2 * n, 2 * nn, zero, Y, 2 * n, 2 * nn, batch); if (rc) return rc;
+    TRX_LAUNCH((block_copy_kernel<T>), g, blk, 0, s, Sn[3], n, nn, Y + n, 2 * n, 2 * nn, n, n, T(1), 0);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sn[1], n, nn, X + n, 2 * n, 2 * nn, one, Y + n, 2 * n, 2 * nn, batch); if (rc) return rc;
+    // S21 = Sm21 + Sm22 Y1 ; S22 = Sm22 Y2
+    TRX_LAUNCH((block_copy_kernel<T>), g, blk, 0, s, Sm[1], n, nn, O[1], n, nn, n, n, T(1), 0);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sm[3], n, nn, Y, 2 * n, 2 * nn, one, O[1], n, nn, batch); if (rc) return rc;
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Sm[3], n, nn, Y + n, 2 * n, 2 * nn, zero, O[3], n, nn, batch); if (rc) return rc;
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+}  // namespace
+}  // namespace trx
+
+using namespace trx;
+
+extern "C" int trx_build_pq(int dtype, const void* E, const void* Einv, const void* Mu, const void* Muinv, const void* kx,
+                            const void* ky, int N, int batch, void* P, void* Q, void* stream) {
+    if (!E || !Einv || !Mu || !Muinv || !kx || !ky || !P || !Q || N <= 0 || batch <= 0) return TRX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRX_C64) return build_pq_t<float>(s, E, Einv, Mu, Muinv, kx, ky, N, batch, P, Q);
+    if (dtype == TRX_C128) return build_pq_t<double>(s, E, Einv, Mu, Muinv, kx, ky, N, batch, P, Q);
+    return TRX_ERR_DTYPE;
+}
+
+extern "C" size_t trx_layer_smatrix_ws_bytes(int dtype, int N, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * 6 * (size_t)batch * (2 * (size_t)N) * (2 * (size_t)N);
+}
+
+extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const void* W, const void* kzfac, const void* vfinv,
+                                 const void* phase, int use_q, int N, int batch, void* S11, void* S21, void* V, void* Cplus,
+                                 void* Cminus, int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
+    if (!W || !kzfac || !vfinv || !phase || !S11 || !S21 || !V || !piv || !info || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
+    if ((use_q && !Q) || (!use_q && !P)) return TRX_ERR_ARG;
+    if ((Cplus == nullptr) != (Cminus == nullptr)) return TRX_ERR_ARG;
+    if (ws_bytes < trx_layer_smatrix_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRX_C64)
+        return layer_smatrix_t<float>(s, (const cx<float>*)P, (const cx<float>*)Q, (const cx<float>*)W, (const cx<float>*)kzfac, (const cx<float>*)vfinv,
+                                      (const cx<float>*)phase, use_q, N, batch, (cx<float>*)S11, (cx<float>*)S21, (cx<float>*)V, (cx<float>*)Cplus,
+                                      (cx<float>*)Cminus, piv, info, (cx<float>*)ws);
+    if (dtype == TRX_C128)
+        return layer_smatrix_t<double>(s, (const cx<double>*)P, (const cx<double>*)Q, (const cx<double>*)W, (const cx<double>*)kzfac, (const cx<double>*)vfinv,
+                                       (const cx<double>*)phase, use_q, N, batch, (cx<double>*)S11, (cx<double>*)S21, (cx<double>*)V, (cx<double>*)Cplus,
+                                       (cx<double>*)Cminus, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}
+
+extern "C" size_t trx_redheffer_ws_bytes(int dtype, int n, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * (size_t)batch * (size_t)n * n;
+}
+
+extern "C" int trx_redheffer(int dtype, const void* const* Sm, const void* const* Sn, void* const* Sout, void* XY, int n, int batch,
+                             int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
+    if (!Sm || !Sn || !Sout || !XY || !piv || !info || !ws || n <= 0 || batch <= 0) return TRX_ERR_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!Sm[k] || !Sn[k] || !Sout[k]) return TRX_ERR_ARG;
+    if (ws_bytes < trx_redheffer_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRX_C64) return redheffer_t<float>(s, (const cx<float>* const*)Sm, (const cx<float>* const*)Sn, (cx<float>* const*)Sout, (cx<float>*)XY, n, batch, piv, info, (cx<float>*)ws);
+    if (dtype == TRX_C128) return redheffer_t<double>(s, (const cx<double>* const*)Sm, (const cx<double>* const*)Sn, (cx<double>* const*)Sout, (cx<double>*)XY, n, batch, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}

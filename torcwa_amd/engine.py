@@ -1,0 +1,187 @@
+"""Thin, batched Python face of the C ABI in include/trx.h.
+
+`Engine` owns nothing but a library handle and a device: every call allocates its outputs/workspaces as torch
+tensors on that device (PyTorch is used only for device memory and streams) and passes raw pointers plus the current
+HIP stream to libtrx.  There is no CPU fallback: the default engine binds torcwa_amd/libtrx.so (gfx950) and requires
+a CUDA/ROCm device.  (The test-suite can inject the kernel-logic emulator build with host tensors; see tests/.)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_CODE = {torch.complex64: _lib.C64, torch.complex128: _lib.C128}
+_REAL = {torch.complex64: torch.float32, torch.complex128: torch.float64}
+
+
+class NumericalError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, lib=None, device=None):
+        if lib is None:
+            lib = _lib.lib()                       # raises TrxError if libtrx.so has not been built
+            if device is None:
+                device = torch.device("cuda")
+            device = torch.device(device)
+            if device.type != "cuda" or not torch.cuda.is_available():
+                raise _lib.TrxError("torcwa_amd runs on an MI355X (ROCm) device only; no CPU path exists. "
+                                    f"Requested device: {device}, torch.cuda.is_available()={torch.cuda.is_available()}")
+        self.lib = lib
+        self.device = torch.device(device if device is not None else "cpu")
+        self.check_info = True
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    @property
+    def stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+    def _ws(self, nbytes):
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+
+    def _ints(self, n):
+        return torch.zeros(int(n), dtype=torch.int32, device=self.device)
+
+    @staticmethod
+    def _c(t):
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _info(self, info, what):
+        if self.check_info:
+            bad = int((info != 0).sum())
+            if bad:
+                raise NumericalError(f"{what}: {bad} of {info.numel()} batch entries reported a numerical failure "
+                                     f"(info={info[info != 0][:8].tolist()})")
+
+    # -- a5 --------------------------------------------------------------------------------------------
+    def convmat(self, grid, ox, oy, dtype):
+        """[B,nx,ny] real/complex grid -> [B,N,N] convolution matrix (torcwa/rcwa.py:1183-1204)."""
+        B, nx, ny = grid.shape
+        cplx = grid.is_complex()
+        grid = self._c(grid.to(dtype if cplx else _REAL[dtype]))
+        N = (2 * ox + 1) * (2 * oy + 1)
+        out = torch.empty((B, N, N), dtype=dtype, device=self.device)
+        nws = self.lib.convmat_ws_bytes(_CODE[dtype], B, nx, ny, ox, oy)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.convmat(_CODE[dtype], int(cplx), grid.data_ptr(), B, nx, ny, ox, oy, out.data_ptr(),
+                                        ws.data_ptr(), nws, self.stream))
+        return out
+
+    # -- dense blocks ----------------------------------------------------------------------------------
+    def gemm(self, A, Bm, *, opA=0, opB=0, alpha=1.0, beta=0.0, out=None):
+        """Batched C = alpha op(A) op(B) + beta C for contiguous [B,*,*] operands."""
+        A, Bm = self._c(A), self._c(Bm)
+        dt = A.dtype
+        Bt = A.shape[0]
+        m = A.shape[1] if opA == 0 else A.shape[2]
+        k = A.shape[2] if opA == 0 else A.shape[1]
+        n = Bm.shape[2] if opB == 0 else Bm.shape[1]
+        if out is None:
+            out = torch.empty((Bt, m, n), dtype=dt, device=self.device)
+        ctype = ctypes.c_double if dt == torch.complex128 else ctypes.c_float
+        al = (ctype * 2)(complex(alpha).real, complex(alpha).imag)
+        be = (ctype * 2)(complex(beta).real, complex(beta).imag)
+        self.lib.check(self.lib.gemm(_CODE[dt], opA, opB, m, n, k, ctypes.addressof(al), A.data_ptr(), A.shape[2],
+                                     A.shape[1] * A.shape[2], Bm.data_ptr(), Bm.shape[2], Bm.shape[1] * Bm.shape[2],
+                                     ctypes.addressof(be), out.data_ptr(), n, m * n, Bt, self.stream))
+        return out
+
+    def inverse(self, A):
+        """Returns inv(A) for [B,n,n] (A is not modified)."""
+        A = A.clone()
+        B, n, _ = A.shape
+        piv, info = self._ints(B * n), self._ints(B)
+        nws = self.lib.inverse_ws_bytes(_CODE[A.dtype], n, B)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.inverse(_CODE[A.dtype], A.data_ptr(), n, B, piv.data_ptr(), info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self._info(info, "inverse")
+        return A
+
+    def solve(self, A, Bm):
+        """Returns X with A X = B ([B,n,n], [B,n,r]); inputs are not modified."""
+        A, X = A.clone(), Bm.clone()
+        B, n, _ = A.shape
+        piv, info = self._ints(B * n), self._ints(B)
+        self.lib.check(self.lib.lu_solve(_CODE[A.dtype], A.data_ptr(), n, X.data_ptr(), X.shape[2], B, piv.data_ptr(), info.data_ptr(), self.stream))
+        self._info(info, "lu_solve")
+        return X
+
+    # -- a7 --------------------------------------------------------------------------------------------
+    def eig(self, A, destroy=False):
+        """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14)."""
+        A = self._c(A) if destroy else A.clone()
+        B, n, _ = A.shape
+        dt = A.dtype
+        w = torch.empty((B, n), dtype=dt, device=self.device)
+        V = torch.empty((B, n, n), dtype=dt, device=self.device)
+        info = self._ints(B)
+        nws = self.lib.eig_ws_bytes(_CODE[dt], n, B)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.eig(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self._info(info, "eig")
+        return w, V
+
+    # -- a6 / a8 / a9 ----------------------------------------------------------------------------------
+    def build_pq(self, E, Einv, M, Minv, kx, ky):
+        B, N, _ = E.shape
+        dt = E.dtype
+        P = torch.empty((B, 2 * N, 2 * N), dtype=dt, device=self.device)
+        Q = torch.empty_like(P)
+        self.lib.check(self.lib.build_pq(_CODE[dt], self._c(E).data_ptr(), self._c(Einv).data_ptr(), self._c(M).data_ptr(), self._c(Minv).data_ptr(),
+                                         self._c(kx).data_ptr(), self._c(ky).data_ptr(), N, B, P.data_ptr(), Q.data_ptr(), self.stream))
+        return P, Q
+
+    def layer_smatrix(self, P, Q, W, kzfac, vfinv, phase, *, use_q=False, want_c=True):
+        """Layer S-matrix (torcwa/rcwa.py:1244-1281).  vfinv: [4,B,N]; returns S11, S21, V, Cplus, Cminus."""
+        B, n, _ = W.shape
+        N = n // 2
+        dt = W.dtype
+        S11 = torch.empty((B, n, n), dtype=dt, device=self.device)
+        S21, V = torch.empty_like(S11), torch.empty_like(S11)
+        cp = torch.empty_like(S11) if want_c else None
+        cm = torch.empty_like(S11) if want_c else None
+        piv, info = self._ints(3 * B * n), self._ints(3 * B)
+        nws = self.lib.layer_smatrix_ws_bytes(_CODE[dt], N, B)
+        ws = self._ws(nws)
+        W, kzfac, vfinv, phase = self._c(W), self._c(kzfac), self._c(vfinv), self._c(phase)
+        self.lib.check(self.lib.layer_smatrix(
+            _CODE[dt], self._c(P).data_ptr() if P is not None else None, self._c(Q).data_ptr() if Q is not None else None,
+            W.data_ptr(), kzfac.data_ptr(), vfinv.data_ptr(), phase.data_ptr(), int(use_q), N, B, S11.data_ptr(), S21.data_ptr(),
+            V.data_ptr(), cp.data_ptr() if want_c else None, cm.data_ptr() if want_c else None, piv.data_ptr(), info.data_ptr(),
+            ws.data_ptr(), nws, self.stream))
+        self._info(info, "layer_smatrix")
+        return S11, S21, V, cp, cm
+
+    def redheffer(self, Sm, Sn):
+        """Star product of two S-matrices given as lists [S11,S21,S12,S22] of [B,n,n] (torcwa/rcwa.py:1283-1306).
+        Returns (Sout list, X1, X2, Y1, Y2) with the four C-propagation factors."""
+        Sm = [self._c(t) for t in Sm]
+        Sn = [self._c(t) for t in Sn]
+        B, n, _ = Sm[0].shape
+        dt = Sm[0].dtype
+        out = [torch.empty((B, n, n), dtype=dt, device=self.device) for _ in range(4)]
+        XY = torch.empty((2, B, n, 2 * n), dtype=dt, device=self.device)
+        piv, info = self._ints(B * n), self._ints(B)
+        nws = self.lib.redheffer_ws_bytes(_CODE[dt], n, B)
+        ws = self._ws(nws)
+        arr = ctypes.c_void_p * 4
+        pm, pn, po = arr(*[t.data_ptr() for t in Sm]), arr(*[t.data_ptr() for t in Sn]), arr(*[t.data_ptr() for t in out])
+        self.lib.check(self.lib.redheffer(_CODE[dt], ctypes.addressof(pm), ctypes.addressof(pn), ctypes.addressof(po), XY.data_ptr(), n, B,
+                                          piv.data_ptr(), info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self._info(info, "redheffer")
+        X, Y = XY[0], XY[1]
+        return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
+
+
+_default = None
+
+
+def default_engine():
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default
