@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""bench.py -- RCWA layer-solves/s on MI355X (BASELINE.json metric), one process per GPU.
+
+Workload (BASELINE.json configs[1]): single patterned layer (Example-1 rectangle 180x100 nm of a-Si:H on glass, 300 nm
+thick, 300x300 grid), Fourier order [15,15] (n = 2N = 1922), wavelength sweep linspace(400,700,128) nm, complex64 I/O.
+A "step" = one pass of the hot path (conv-matrix -> P,Q -> eig -> layer S-matrix -> Redheffer with the input half
+space -> S-parameter read-out) over one batch of `--batch` sweep points whose permittivity grids are already resident
+in HBM.  N GPUs: every rank runs its own batch (weak scaling, no data-path collective); the only communication is
+the final all_gather of the S-parameters (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def make_inputs(batch, order, device, rank, seed_shift=0):
+    from torcwa_amd.sweep import asih_eps_table, rectangle_density
+    lam, eps_si = asih_eps_table()
+    idx = (np.arange(batch) + rank * batch + seed_shift) % len(lam)
+    lam_b, eps_b = lam[idx], eps_si[idx]
+    dens = rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., dtype=torch.float32, device=device)
+    eps_t = torch.as_tensor(eps_b, dtype=torch.complex64, device=device)
+    grids = dens[None] * eps_t[:, None, None] + (1. - dens[None])            # complex64 [B,300,300], as a c64 user builds it
+    freq = torch.as_tensor(1.0 / lam_b, dtype=torch.float64, device=device)
+    return freq, grids.contiguous(), lam_b
+
+
+def run_step(freq, grids, order, engine, precision, chunk):
+    from torcwa_amd.sweep import solve_single_layer_sweep
+    return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
+                                    precision=precision, engine=engine, chunk=chunk, check_info=False)
+
+
+def cpu_baseline(order, lam_nm, eps_si, threads):
+    """The reference's CPU path (oracle port, same op sequence), timed on the host cores on a bounded sample."""
+    from oracle import rcwa_oracle as orc
+    torch.set_num_threads(threads)
+    dens = orc.rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., dtype=torch.float32)
+    eps = (dens * complex(eps_si) + (1. - dens)).to(torch.complex64)
+    t0 = time.perf_counter()
+    s, lays, S, C = orc.solve_stack(1.0 / float(lam_nm), order, [300., 300.], [(300., eps, 1.0)], dtype=torch.complex64, eps_in=1.46 ** 2)
+    v = orc.s_parameters(s, S, [0, 0])
+    dt = time.perf_counter() - t0
+    return dt, complex(v[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="sweep points per step per GPU")
+    ap.add_argument("--order", type=int, default=15)
+    ap.add_argument("--chunk", type=int, default=0, help="points solved concurrently (0 = whole batch)")
+    ap.add_argument("--precision", default="high", choices=["high", "native"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import torcwa_amd
+    from torcwa_amd.sweep import gather_sweep
+    engine = torcwa_amd.Engine(device=device)
+    order = [args.order, args.order]
+    n = 2 * (2 * args.order + 1) ** 2
+    chunk = args.chunk if args.chunk > 0 else args.batch
+    freq, grids, lam_b = make_inputs(args.batch, order, device, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = run_step(freq, grids, order, engine, args.precision, chunk)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run_step(freq, grids, order, engine, args.precision, chunk)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        full = gather_sweep(out, args.batch * world)       # the one collective of the job: final gather (RCCL)
+    else:
+        full = out
+    total_solves = args.batch * world * args.steps
+    value = total_solves / elapsed
+
+    if rank == 0:
+        res = {
+            "metric": "RCWA layer-solves/sec (complex64 I/O) at Fourier order [%d,%d]" % (args.order, args.order),
+            "value": value, "unit": "layer-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "c128 arithmetic (complex64 I/O)" if args.precision == "high" else "c64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single patterned layer, order=[%d,%d] (n=%d), 300x300 grid, %d-lambda sweep per GPU, "
+                                   "glass input half-space" % (args.order, args.order, n, args.batch),
+                       "batch_per_gpu": args.batch, "chunk": chunk, "precision": args.precision},
+            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)],
+        }
+        res["roofline"] = None
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads if args.cpu_threads > 0 else max(1, (os.cpu_count() or 2) // 2)
+            from torcwa_amd.sweep import asih_eps_table
+            lam, eps_si = asih_eps_table()
+            dt, v = cpu_baseline(order, lam[0], eps_si[0], threads)
+            res["cpu_baseline"] = {"value": 1.0 / dt, "unit": "layer-solves/s", "cores": threads, "kind": "port",
+                                   "sample": "1 layer-solve (lambda=%.1f nm) of the same workload, complex64, oracle/rcwa_oracle.py on torch-CPU; "
+                                             "txx00=%.6f%+.6fj" % (lam[0], v.real, v.imag)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Sweep driver: the reference's user-level `for` loop over sweep points (example/Example1.ipynb lambda sweep,
+example/Example3.ipynb (Wx,Wy) sweep) as one batched, optionally multi-GPU job.
+
+Sharding: sweep points are independent, so rank r of R owns a contiguous block of the flattened sweep
+(`shard_range`); there is no data-path collective.  The only communication is one all_gather of the requested
+S-parameters at the end (`gather_sweep`, RCCL over xGMI on GPUs; payload is a few KB, latency-bound).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .batched import BatchedRCWA
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ in size by at most one."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_sweep(local, n_items, group=None):
+    """all_gather of per-point results: `local` is this rank's [m_r, ...] block (m_r from shard_range).  Returns the
+    full [n_items, ...] tensor on every rank.  Works with unequal block sizes (pads to the largest block)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_range(n_items, r, world) for r in range(world)]
+    mmax = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    if pad.is_complex():
+        buf = torch.view_as_real(pad).contiguous()
+    else:
+        buf = pad.contiguous()
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    parts = []
+    for r, (lo, hi) in enumerate(sizes):
+        t = out[r][: hi - lo]
+        parts.append(torch.view_as_complex(t) if pad.is_complex() else t)
+    return torch.cat(parts, dim=0)
+
+
+def asih_eps_table():
+    """eps(lambda) of a-Si:H on linspace(400,700,128) nm (values of example/Materials.py `aSiH.apply(l)**2`, stored as data)."""
+    z = np.load(os.path.join(_DATA, "asih_eps_400_700_128.npz"))
+    return z["lam"], z["eps"]
+
+
+def rectangle_density(nx, ny, Lx, Ly, Wx, Wy, Cx, Cy, theta=0.0, edge_sharpness=1000.0, dtype=torch.float64, device="cpu"):
+    from .geometry import geometry
+    g = geometry(Lx=Lx, Ly=Ly, nx=nx, ny=ny, edge_sharpness=edge_sharpness, dtype=dtype, device=torch.device(device))
+    return g.rectangle(Wx=Wx, Wy=Wy, Cx=Cx, Cy=Cy, theta=theta)
+
+
+def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0,
+                             dtype=torch.complex64, precision="high", engine=None, chunk=None, orders=((0, 0),),
+                             polarization="xx", direction="forward", port="transmission", check_info=True):
+    """B sweep points of a 1-patterned-layer stack (config 2/4 of BASELINE.json).  freq [B], eps_grids [B,nx,ny].
+    Returns the requested S-parameter [B, len(orders)]."""
+    B = freq.shape[0]
+    chunk = B if chunk is None else int(chunk)
+    outs = []
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        sim = BatchedRCWA(freq[lo:hi], order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
+        sim.engine.check_info = check_info
+        if eps_in is not None:
+            sim.add_input_layer(eps=eps_in)
+        if eps_out is not None:
+            sim.add_output_layer(eps=eps_out)
+        sim.set_incident_angle(inc_ang, azi_ang)
+        th = thickness[lo:hi] if torch.is_tensor(thickness) and thickness.dim() > 0 else thickness
+        sim.add_layer(th, eps_grids[lo:hi])
+        sim.solve_global_smatrix()
+        outs.append(sim.S_parameters([list(o) for o in orders], direction=direction, port=port, polarization=polarization))
+        del sim
+    return torch.cat(outs, dim=0)
