@@ -16,6 +16,7 @@
 //   apply_left_kernel  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n]
 //   apply_right_kernel H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U
 #include "eig.hpp"
+#include "mfma.hpp"
 
 namespace trx {
 namespace {
@@ -347,14 +348,23 @@ __global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall
     if (t == 0) { st_all[b].tau = tau_end + 1; st_all[b].w0 = w0; st_all[b].w1 = w1; }
 }
 
+// Slab updates on the matrix cores.  Both kernels multiply a 64-wide slab by the window unitary U (ww <= 64) with
+// cmma_tile_strided (mfma.hpp): operands are staged as split re/im planes in two K-chunks of 32 so that two
+// workgroups fit in a CU's 160 KiB of LDS; each of the 4 waves owns 16 rows x 64 columns of the output slab.
+constexpr int KC = 32;            // K chunk
+constexpr int ALD = KC + 2;       // k-contiguous plane stride   (element (major,k) at [major*ALD + k])
+constexpr int MLD = 72;           // major-contiguous plane stride (element (major,k) at [k*MLD + major])
+constexpr int APLANE = (64 * ALD > KC * MLD) ? 64 * ALD : KC * MLD;
+
 // H[w0:w1, cs:cs+64) <- U^H H[w0:w1, cs:cs+64),  cs = w1 + 64*blockIdx.x
 template <class T>
 __global__ __launch_bounds__(256) void apply_left_kernel(cx<T>* __restrict__ Aall, int n, const QrState* __restrict__ st_all,
                                                          const cx<T>* __restrict__ Uall) {
     TRX_DYN_SMEM(smem);
-    constexpr int LD = QW + 1;
-    cx<T>* Us = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
-    cx<T>* Xs = Us + QW * LD;                          // [QW][LD]
+    T* Ar = reinterpret_cast<T*>(smem);       // (U^H)[i][k] = conj(U[k][i]) : i-contiguous  [k*MLD + i]
+    T* Ai = Ar + APLANE;
+    T* Br = Ai + APLANE;                      // X[k][col] : col-contiguous  [k*MLD + col]
+    T* Bi = Br + APLANE;
     const int b = blockIdx.y;
     const int w0 = st_all[b].w0, w1 = st_all[b].w1;
     const int ww = w1 - w0;
@@ -363,27 +373,37 @@ __global__ __launch_bounds__(256) void apply_left_kernel(cx<T>* __restrict__ Aal
     const int nc = (n - cs < 64) ? n - cs : 64;
     cx<T>* H = Aall + (long)b * n * n;
     const cx<T>* U = Uall + (long)b * QW * QW;
-    const int t = threadIdx.x;
-    for (int e = t; e < ww * ww; e += 256) { const int r = e / ww, c = e - r * ww; Us[r * LD + c] = U[r * QW + c]; }
-    for (int e = t; e < ww * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        Xs[r * LD + c] = (c < nc) ? H[(long)(w0 + r) * n + cs + c] : cx<T>(T(0), T(0));
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    typename Mfma<T>::acc_t accR[4], accI[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
+    for (int kc = 0; kc < ww; kc += KC) {
+        for (int e = t; e < KC * 64; e += 256) {
+            const int kk = e >> 6, c = e & 63;
+            const int k = kc + kk;
+            cx<T> u(T(0), T(0)), x(T(0), T(0));
+            if (k < ww) {
+                if (c < ww) u = U[k * QW + c];
+                if (c < nc) x = H[(long)(w0 + k) * n + cs + c];
+            }
+            Ar[kk * MLD + c] = u.x; Ai[kk * MLD + c] = -u.y;
+            Br[kk * MLD + c] = x.x; Bi[kk * MLD + c] = x.y;
+        }
+        __syncthreads();
+        cmma_tile_strided<T, 4>(Ar, Ai, 1, MLD, 16 * wave, Br, Bi, MLD, 1, 0, KC, accR, accI);
+        __syncthreads();
     }
-    __syncthreads();
-    const int c = t & 63, rg = t >> 6;
-    cx<T> acc[16];
+    const int cl = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = cx<T>(T(0), T(0));
-    for (int kk = 0; kk < ww; ++kk) {
-        const cx<T> x = Xs[kk * LD + c];
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + Mfma<T>::crow(lane, r);
+        if (row >= ww) continue;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cfma_conj(acc[i], Us[kk * LD + rg * 16 + i], x);
-    }
-    if (c < nc) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = rg * 16 + i;
-            if (r < ww) H[(long)(w0 + r) * n + cs + c] = acc[i];
+        for (int j = 0; j < 4; ++j) {
+            const int c = 16 * j + cl;
+            if (c < nc) H[(long)(w0 + row) * n + cs + c] = cx<T>(accR[j][r], accI[j][r]);
         }
     }
 }
@@ -393,9 +413,10 @@ template <class T>
 __global__ __launch_bounds__(256) void apply_right_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n, int nslab,
                                                           const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall) {
     TRX_DYN_SMEM(smem);
-    constexpr int LD = QW + 1;
-    cx<T>* Us = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
-    cx<T>* Xs = Us + QW * LD;                          // [64][LD]
+    T* Ar = reinterpret_cast<T*>(smem);       // X[row][k] : k-contiguous  [row*ALD + k]
+    T* Ai = Ar + APLANE;
+    T* Br = Ai + APLANE;                      // U[k][col] : col-contiguous  [k*MLD + col]
+    T* Bi = Br + APLANE;
     const int b = blockIdx.y;
     const int w0 = st_all[b].w0, w1 = st_all[b].w1;
     const int ww = w1 - w0;
@@ -407,27 +428,43 @@ __global__ __launch_bounds__(256) void apply_right_kernel(cx<T>* __restrict__ Aa
     const int nr = (rend - rs < 64) ? rend - rs : 64;
     cx<T>* X = (isZ ? Zall : Aall) + (long)b * n * n;
     const cx<T>* U = Uall + (long)b * QW * QW;
-    const int t = threadIdx.x;
-    for (int e = t; e < ww * ww; e += 256) { const int r = e / ww, c = e - r * ww; Us[r * LD + c] = U[r * QW + c]; }
-    for (int e = t; e < 64 * ww; e += 256) {
-        const int r = e / ww, c = e - r * ww;
-        Xs[r * LD + c] = (r < nr) ? X[(long)(rs + r) * n + w0 + c] : cx<T>(T(0), T(0));
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    typename Mfma<T>::acc_t accR[4], accI[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
+    for (int kc = 0; kc < ww; kc += KC) {
+        for (int e = t; e < 64 * KC; e += 256) {
+            {   // X slab: lanes run along k (contiguous in global memory)
+                const int row = e / KC, kk = e - row * KC;
+                const int k = kc + kk;
+                cx<T> x(T(0), T(0));
+                if (row < nr && k < ww) x = X[(long)(rs + row) * n + w0 + k];
+                Ar[row * ALD + kk] = x.x; Ai[row * ALD + kk] = x.y;
+            }
+            {   // U chunk: lanes run along the column
+                const int kk = e >> 6, c = e & 63;
+                const int k = kc + kk;
+                cx<T> u(T(0), T(0));
+                if (k < ww && c < ww) u = U[k * QW + c];
+                Br[kk * MLD + c] = u.x; Bi[kk * MLD + c] = u.y;
+            }
+        }
+        __syncthreads();
+        cmma_tile_strided<T, 4>(Ar, Ai, ALD, 1, 16 * wave, Br, Bi, MLD, 1, 0, KC, accR, accI);
+        __syncthreads();
     }
-    __syncthreads();
-    const int c = t & 63, rg = t >> 6;
-    if (c >= ww) return;
-    cx<T> acc[16];
+    const int cl = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = cx<T>(T(0), T(0));
-    for (int kk = 0; kk < ww; ++kk) {
-        const cx<T> u = Us[kk * LD + c];
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + Mfma<T>::crow(lane, r);
+        if (row >= nr) continue;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cfma(acc[i], Xs[(rg * 16 + i) * LD + kk], u);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = rg * 16 + i;
-        if (r < nr) X[(long)(rs + r) * n + w0 + c] = acc[i];
+        for (int j = 0; j < 4; ++j) {
+            const int c = 16 * j + cl;
+            if (c < ww) X[(long)(rs + row) * n + w0 + c] = cx<T>(accR[j][r], accI[j][r]);
+        }
     }
 }
 
@@ -444,8 +481,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     constexpr int LD = QW + 1;
     const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
     const size_t smw = sm2 + sizeof(Rot<T>) * QNS + sizeof(int) * 2 * QNS + sizeof(QrState);
-    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_left_kernel<T>, sm2) ||
-        set_max_dyn_smem((const void*)apply_right_kernel<T>, sm2))
+    const size_t sma = sizeof(T) * 4 * APLANE;
+    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_left_kernel<T>, sma) ||
+        set_max_dyn_smem((const void*)apply_right_kernel<T>, sma))
         return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
     const int max_sweeps = 30 * n + 100;
@@ -461,8 +499,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 1 : 1;
         for (int q = 0; q < nwin; ++q) {
             TRX_LAUNCH((qr_window_kernel<T>), dim3(batch), dim3(256), smw, s, B.A, n, B.st, B.U, (const cx<T>*)B.shifts);
-            TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sm2, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U);
-            TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sm2, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U);
+            TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sma, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U);
+            TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sma, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U);
         }
     }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch);

@@ -1,23 +1,30 @@
-// Batched complex GEMM, row-major interleaved complex: C = alpha*op(A)*op(B) + beta*C.
+// Batched complex GEMM, row-major interleaved complex: C = alpha*op(A)*op(B) + beta*C, on the CDNA4 matrix cores.
 // Replaces the torch.matmul call sites of the reference hot path (torcwa/rcwa.py:1161-1164, 1226-1232,
-// 1236, 1260-1281, 1287-1304).
+// 1236, 1260-1281, 1287-1304) and serves every block update of the LU and eigensolver kernels.
 //
-// v1 kernel: LDS-tiled 64x64x16, 256 threads, 4x4 complex accumulators per thread, register-prefetched
-// global->LDS staging.  (The MFMA kernel lives in gemm_mfma.hip and is selected by gemm<T>() when enabled.)
-#include "common.hpp"
+// Kernel: 64x64 block tile, BK = 16, 256 threads = 4 waves, wave w owns rows [16w,16w+16) x 64 columns
+// (4 MFMA tiles, complex accumulators = 32 acc registers).  Operands are staged through LDS as split re/im
+// planes whose in-LDS orientation follows the operand's global orientation, so that both the global->LDS copy
+// and the MFMA fragment reads are contiguous / bank-conflict free (see mfma.hpp); the next K-slab is prefetched
+// into registers while the current one is multiplied.
+#include "mfma.hpp"
 
 namespace trx {
 
 namespace {
-constexpr int BM = 64, BN = 64, BK = 16, TM = 4, TN = 4;
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDK = BK + 2;      // k-contiguous plane: element (major, k) at [major*LDK + k]
+constexpr int LDM = 80;          // major-contiguous plane: element (major, k) at [k*LDM + major]
+constexpr int PLANE = 1280;      // max(64*LDK, 16*LDM)
 
 template <class T, int OPA, int OPB>
-__global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A,
-                                                   int lda, long sA, const cx<T>* __restrict__ B, int ldb, long sB,
-                                                   cx<T> beta, cx<T>* __restrict__ C, int ldc, long sC,
-                                                   const GemmDesc* __restrict__ desc) {
-    __shared__ cx<T> As[BK][BM + 1];
-    __shared__ cx<T> Bs[BK][BN + 1];
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
+                                                        const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
+                                                        int ldc, long sC, const GemmDesc* __restrict__ desc) {
+    __shared__ T Ar[PLANE];
+    __shared__ T Ai[PLANE];
+    __shared__ T Br[PLANE];
+    __shared__ T Bi[PLANE];
     const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
@@ -30,80 +37,73 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, cx<T> al
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= m || n0 >= n) return;
     const int t = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;
-
-    cx<T> acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = cx<T>(T(0), T(0));
+    constexpr bool A_KC = (OPA == TRX_OP_N);     // A's k index is contiguous in global memory
+    constexpr bool B_KC = (OPB != TRX_OP_N);     // B's k index is contiguous in global memory
+    constexpr int sAr = A_KC ? LDK : 1, sAk = A_KC ? 1 : LDM;
+    constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDM;
 
     cx<T> ra[4], rb[4];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = t + 256 * r;
-            // A tile: BM x BK
-            int row, kk;
-            if (OPA == TRX_OP_N) { row = e >> 4; kk = e & 15; } else { kk = e >> 6; row = e & 63; }
-            cx<T> v(T(0), T(0));
-            if (m0 + row < m && k0 + kk < k) {
-                if (OPA == TRX_OP_N) v = A[(long)(m0 + row) * lda + k0 + kk];
-                else { v = A[(long)(k0 + kk) * lda + m0 + row]; if (OPA == TRX_OP_C) v = conj(v); }
+            {
+                const int row = A_KC ? (e >> 4) : (e & 63), kk = A_KC ? (e & 15) : (e >> 6);
+                cx<T> v(T(0), T(0));
+                if (m0 + row < m && k0 + kk < k) {
+                    if (OPA == TRX_OP_N) v = A[(long)(m0 + row) * lda + k0 + kk];
+                    else { v = A[(long)(k0 + kk) * lda + m0 + row]; if (OPA == TRX_OP_C) v = conj(v); }
+                }
+                ra[r] = v;
             }
-            ra[r] = v;
-            // B tile: BK x BN
-            int col, kb;
-            if (OPB == TRX_OP_N) { kb = e >> 6; col = e & 63; } else { col = e >> 4; kb = e & 15; }
-            cx<T> w(T(0), T(0));
-            if (n0 + col < n && k0 + kb < k) {
-                if (OPB == TRX_OP_N) w = B[(long)(k0 + kb) * ldb + n0 + col];
-                else { w = B[(long)(n0 + col) * ldb + k0 + kb]; if (OPB == TRX_OP_C) w = conj(w); }
+            {
+                const int col = B_KC ? (e >> 4) : (e & 63), kk = B_KC ? (e & 15) : (e >> 6);
+                cx<T> v(T(0), T(0));
+                if (n0 + col < n && k0 + kk < k) {
+                    if (OPB == TRX_OP_N) v = B[(long)(k0 + kk) * ldb + n0 + col];
+                    else { v = B[(long)(n0 + col) * ldb + k0 + kk]; if (OPB == TRX_OP_C) v = conj(v); }
+                }
+                rb[r] = v;
             }
-            rb[r] = w;
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = t + 256 * r;
-            int row, kk, col, kb;
-            if (OPA == TRX_OP_N) { row = e >> 4; kk = e & 15; } else { kk = e >> 6; row = e & 63; }
-            if (OPB == TRX_OP_N) { kb = e >> 6; col = e & 63; } else { col = e >> 4; kb = e & 15; }
-            As[kk][row] = ra[r];
-            Bs[kb][col] = rb[r];
+            const int row = A_KC ? (e >> 4) : (e & 63), ka = A_KC ? (e & 15) : (e >> 6);
+            const int col = B_KC ? (e >> 4) : (e & 63), kb = B_KC ? (e & 15) : (e >> 6);
+            Ar[row * sAr + ka * sAk] = ra[r].x; Ai[row * sAr + ka * sAk] = ra[r].y;
+            Br[col * sBc + kb * sBk] = rb[r].x; Bi[col * sBc + kb * sBk] = rb[r].y;
         }
     };
 
+    typename Mfma<T>::acc_t accR[4], accI[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
+
+    const int wave = t >> 6, lane = t & 63;
     load_tiles(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
         store_tiles();
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; ++kk) {
-            cx<T> a[TM], bb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bb[j] = Bs[kk][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) cfma(acc[i][j], a[i], bb[j]);
-        }
+        cmma_tile_strided<T, 4>(Ar, Ai, sAr, sAk, 16 * wave, Br, Bi, sBk, sBc, 0, BK, accR, accI);
         __syncthreads();
     }
     const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
+    const int col_l = lane & 15;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + ty + 16 * i;
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wave + Mfma<T>::crow(lane, r);
         if (row >= m) continue;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + tx + 16 * j;
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 16 * j + col_l;
             if (col >= n) continue;
-            cx<T> v = alpha * acc[i][j];
+            cx<T> v = alpha * cx<T>(accR[j][r], accI[j][r]);
             cx<T>* p = C + (long)row * ldc + col;
             if (has_beta) v += beta * (*p);
             *p = v;
@@ -115,9 +115,9 @@ template <class T, int OPA>
 int launch_b(hipStream_t s, int opB, dim3 grid, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
              const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc) {
     switch (opB) {
-        case TRX_OP_N: TRX_LAUNCH((gemm_kernel<T, OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
-        case TRX_OP_T: TRX_LAUNCH((gemm_kernel<T, OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
-        case TRX_OP_C: TRX_LAUNCH((gemm_kernel<T, OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
+        case TRX_OP_N: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
+        case TRX_OP_T: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
+        case TRX_OP_C: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
         default: return TRX_ERR_ARG;
     }
     TRX_CHECK_LAUNCH();
