@@ -54,6 +54,46 @@ def cpu_baseline(order, lam_nm, eps_si, threads):
     return dt, complex(v[0])
 
 
+# MI355X dense matrix-core peaks for the arithmetic type of the path.  f32: 157.3 TF (MI355X_MICROARCH.md, "Peak FP32
+# (matrix)"); f64: 78.6 TF (AMD MI355X datasheet; the guide only states that the f32 matrix rate equals the vector rate
+# and f64 runs at half of it).  HBM3E: 8 TB/s spec.
+PEAK_TFLOPS = {"high": 78.6, "native": 157.3}
+PEAK_HBM_GBS = 8000.0
+
+
+def roofline(engine, precision, elapsed):
+    """Live figures from the HIP events libtrx recorded around its dominant kernels during the timed region."""
+    import ctypes
+    tags = []
+    for tag in range(6):
+        buf = (ctypes.c_double * 6)()
+        engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
+        launches, timed, flops, nbytes, ms, flops_all = list(buf)
+        tags.append({"kernel": engine.lib.prof_tag_name(tag).decode(), "launches": int(launches), "timed_launches": int(timed),
+                     "ms_timed": ms, "flops_timed": flops, "bytes_timed": nbytes})
+    times = [{"kernel": t["kernel"], "launches": t["launches"], "timed_launches": t["timed_launches"],
+              "avg_us": (1e3 * t["ms_timed"] / t["timed_launches"]) if t["timed_launches"] else None,
+              "share_of_wall": (t["ms_timed"] * (t["launches"] / max(t["timed_launches"], 1)) / (1e3 * elapsed)) if t["timed_launches"] else None}
+             for t in tags]
+    # dominant kernel with a known algorithmic work figure: the N,N complex GEMM on the matrix cores
+    g = tags[0]
+    roof = None
+    if g["timed_launches"] > 0 and g["ms_timed"] > 0:
+        ach = g["flops_timed"] / (g["ms_timed"] * 1e-3) / 1e12
+        roof = {"kernel": g["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[precision], "traffic": None,
+                "avg_launch_us": 1e3 * g["ms_timed"] / g["timed_launches"], "launches_timed": g["timed_launches"],
+                "algorithmic_flops_per_launch": g["flops_timed"] / g["timed_launches"],
+                "algorithmic_bytes_per_launch": g["bytes_timed"] / g["timed_launches"],
+                "note": "8 real flops per complex MAC x m*n*k*batch of each launch; events on the launch stream"}
+        h = tags[5]
+        if h["timed_launches"] > 0 and h["ms_timed"] > 0:
+            gbs = h["bytes_timed"] / (h["ms_timed"] * 1e-3) / 1e9
+            roof["secondary"] = {"kernel": h["kernel"], "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * h["ms_timed"] / h["timed_launches"]}
+    return roof, times
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,11 +133,15 @@ def main():
     for _ in range(args.warmup):
         out = run_step(freq, grids, order, engine, args.precision, chunk)
     barrier()
+    # HIP-event timing of the dominant kernels, recorded by libtrx on the launch stream during the timed region
+    engine.lib.prof_reset()
+    engine.lib.prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run_step(freq, grids, order, engine, args.precision, chunk)
     barrier()
     elapsed = time.perf_counter() - t0
+    engine.lib.prof_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -120,7 +164,7 @@ def main():
                        "batch_per_gpu": args.batch, "chunk": chunk, "precision": args.precision},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)],
         }
-        res["roofline"] = None
+        res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed)
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads if args.cpu_threads > 0 else max(1, (os.cpu_count() or 2) // 2)
             from torcwa_amd.sweep import asih_eps_table

@@ -95,6 +95,17 @@ size_t trx_redheffer_ws_bytes(int dtype, int n, int batch);
 int trx_redheffer(int dtype, const void* const* Sm, const void* const* Sn, void* const* Sout, void* XY, int n, int batch,
                   int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- measurement aid (no reference counterpart): HIP-event timing of the dominant kernels --------------------
+ * trx_prof_enable(1) makes the instrumented launch sites record hipEvents on the launch stream (pool of 4096 per
+ * tag; launches beyond the pool are counted but not timed).  trx_prof_get(tag, out[6]) waits for those events and
+ * returns {launches, timed_launches, algorithmic flops of the timed launches, algorithmic bytes of the timed
+ * launches, milliseconds of the timed launches, flops of all launches}.  Tags: 0 gemm N,N; 1 gemm other ops;
+ * 2 QR apply_left; 3 QR apply_right; 4 QR window; 5 Hessenberg gemv. */
+int trx_prof_enable(int on);
+int trx_prof_reset(void);
+int trx_prof_get(int tag, double* out);
+const char* trx_prof_tag_name(int tag);
+
 #ifdef __cplusplus
 }
 #endif

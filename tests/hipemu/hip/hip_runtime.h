@@ -46,6 +46,11 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp,
     return 0;
 }
 
+typedef void* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 

@@ -9,6 +9,7 @@
 //                     v broadcast from LDS)  -- HBM-bound, n^3/3 element reads per matrix in total.
 //   gemm              all block updates (right/left trailing updates and the Z accumulation).
 #include "eig.hpp"
+#include "prof.hpp"
 
 namespace trx {
 namespace {
@@ -204,6 +205,8 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
             if (c < ib) {
                 const int j = p0 + c;
                 const int rpb = 32;
+                // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
+                ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
                 TRX_LAUNCH((hess_gemv_kernel<T>), dim3(cdiv_i(nr, rpb), batch), dim3(256), sizeof(cx<T>) * (size_t)(n - j - 1), s,
                            (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
             }

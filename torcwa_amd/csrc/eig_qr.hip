@@ -17,6 +17,7 @@
 //   apply_right_kernel H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U
 #include "eig.hpp"
 #include "mfma.hpp"
+#include "prof.hpp"
 
 namespace trx {
 namespace {
@@ -498,9 +499,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (summary[0] == 0) break;
         const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 1 : 1;
         for (int q = 0; q < nwin; ++q) {
-            TRX_LAUNCH((qr_window_kernel<T>), dim3(batch), dim3(256), smw, s, B.A, n, B.st, B.U, (const cx<T>*)B.shifts);
-            TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sma, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U);
-            TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sma, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U);
+            { ProfScope p(PROF_QR_WINDOW, s, 0, 0);
+              TRX_LAUNCH((qr_window_kernel<T>), dim3(batch), dim3(256), smw, s, B.A, n, B.st, B.U, (const cx<T>*)B.shifts); }
+            { ProfScope p(PROF_QR_APPLY_LEFT, s, 0, 0);
+              TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sma, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U); }
+            { ProfScope p(PROF_QR_APPLY_RIGHT, s, 0, 0);
+              TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sma, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U); }
         }
     }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch);

@@ -8,6 +8,7 @@
 // and the MFMA fragment reads are contiguous / bank-conflict free (see mfma.hpp); the next K-slab is prefetched
 // into registers while the current one is multiplied.
 #include "mfma.hpp"
+#include "prof.hpp"
 
 namespace trx {
 
@@ -130,6 +131,11 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
          const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc) {
     if (m <= 0 || n <= 0 || batch <= 0) return TRX_OK;
     dim3 grid(cdiv_i(n, BN), cdiv_i(m, BM), batch);
+    // algorithmic work of this launch: 8 real flops per complex MAC; bytes = A + B read once, C written (+read if beta)
+    const double macs = (double)m * n * k * batch;
+    const double el = (double)sizeof(cx<T>) * batch;
+    ProfScope prof((opA == TRX_OP_N && opB == TRX_OP_N) ? PROF_GEMM_NN : PROF_GEMM_OTHER, s, desc ? 0.0 : 8.0 * macs,
+                   desc ? 0.0 : el * ((double)m * k + (double)k * n + (double)m * n * ((beta.x != T(0) || beta.y != T(0)) ? 2 : 1)));
     switch (opA) {
         case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc);
         case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc);

@@ -1,0 +1,26 @@
+// Optional in-library kernel timing with HIP events (used by bench.py for the live roofline figure).
+// When enabled, instrumented launch sites bracket the kernel with hipEventRecord on the SAME stream the kernel is
+// launched on; trx_prof_get() synchronises those events and returns launches / algorithmic flops / bytes / time.
+#pragma once
+#include "common.hpp"
+
+namespace trx {
+enum ProfTag { PROF_GEMM_NN = 0, PROF_GEMM_OTHER = 1, PROF_QR_APPLY_LEFT = 2, PROF_QR_APPLY_RIGHT = 3, PROF_QR_WINDOW = 4,
+               PROF_HESS_GEMV = 5, PROF_NTAGS = 6 };
+
+bool prof_enabled();
+// returns an event-slot handle (>= 0) or -1 when disabled / pool exhausted; records the start event
+int prof_begin(int tag, hipStream_t s, double flops, double bytes);
+void prof_end(int tag, int slot, hipStream_t s);
+
+struct ProfScope {
+    int tag, slot;
+    hipStream_t s;
+    ProfScope(int tag_, hipStream_t s_, double flops, double bytes) : tag(tag_), slot(-1), s(s_) {
+        if (prof_enabled()) slot = prof_begin(tag, s, flops, bytes);
+    }
+    ~ProfScope() {
+        if (slot >= 0) prof_end(tag, slot, s);
+    }
+};
+}  // namespace trx
