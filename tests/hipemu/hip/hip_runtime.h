@@ -251,6 +251,7 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
     if (s < 0 || (s & ~(width - 1)) != (l & ~(width - 1))) s = l;
     return ::hipemu::wave_read<T>(s);
 }
+inline void __builtin_amdgcn_wave_barrier() { ::hipemu::wave_post<int>(0); }
 inline unsigned long long __ballot(int pred) {
     ::hipemu::wave_post<int>(pred ? 1 : 2);          // 2 = participated, false; 0 = stale/not participating
     unsigned long long m = 0;

@@ -288,3 +288,170 @@ if __name__ == "__main__":
         w, V, ok = eig(A, stats=st)
         print("   eig ok", ok, "resid", np.abs(A @ V - V * w).max(), "sweeps", st.get("sweeps"),
               "eigval err", np.abs(np.sort_complex(w) - np.sort_complex(np.linalg.eigvals(A))).max())
+
+
+# ------------------------------------------------------------------------------------------------------
+# Aggressive early deflation (Braman/Byers/Mathias; LAPACK zlaqr3 simplified) -- prototype for eig_qr.hip
+# ------------------------------------------------------------------------------------------------------
+def _swap_adjacent(T, V, k):
+    """Swap T[k,k] and T[k+1,k+1] of an upper-triangular T by one rotation (ztrexc for complex)."""
+    a, b = T[k, k], T[k + 1, k + 1]
+    c, s, _ = rotg(T[k, k + 1], b - a)
+    G = np.array([[c, s], [-np.conj(s), c]])
+    T[k:k + 2, k:] = G @ T[k:k + 2, k:]
+    T[:k + 2, k:k + 2] = T[:k + 2, k:k + 2] @ G.conj().T
+    T[k + 1, k] = 0.0
+    V[:, k:k + 2] = V[:, k:k + 2] @ G.conj().T
+
+
+def aed_step(H, Z, ilo, ihi, nw):
+    """One AED on the trailing nw x nw window of the active block.  Returns (nd, shifts)."""
+    n = H.shape[0]
+    eps = np.finfo(np.float64).eps
+    smlnum = np.finfo(np.float64).tiny * (n / eps)
+    nw = min(nw, ihi - ilo + 1)
+    kw = ihi - nw + 1
+    s = H[kw, kw - 1] if kw > ilo else 0.0
+    T, V, ok = small_schur(H[kw:ihi + 1, kw:ihi + 1])
+    T = np.triu(T)
+    if not ok:
+        return 0, np.diag(T).copy()
+    ns = nw
+    ilst = 0
+    while ilst < ns:
+        foo = abs(T[ns - 1, ns - 1].real) + abs(T[ns - 1, ns - 1].imag)
+        if foo == 0:
+            foo = abs(s)
+        spike = abs((s * V[0, ns - 1]).real) + abs((s * V[0, ns - 1]).imag)
+        if spike <= max(smlnum, eps * foo):
+            ns -= 1                       # deflatable
+        else:
+            for k in range(ns - 2, ilst - 1, -1):     # move it to position ilst
+                _swap_adjacent(T, V, k)
+            ilst += 1
+    if ns == 0:
+        s = 0.0
+    nd = nw - ns
+    if nd == 0:
+        return 0, np.diag(T).copy()       # nothing deflated: H untouched, window eigenvalues are the shifts
+    if ns > 1 and s != 0:
+        # reflector reducing the spike s*conj(V[0,0:ns]) to a multiple of e1, then Hessenberg restore of T[0:ns,0:ns]
+        work = np.conj(V[0, :ns]).copy()
+        beta, tau, v = larfg(work)
+        Hh = np.eye(ns, dtype=np.complex128) - tau * np.outer(v, v.conj())
+        # T <- Hh^H T Hh on the leading ns rows/cols (all nw columns for the left side), V <- V Hh
+        T[:ns, :] = Hh.conj().T @ T[:ns, :]
+        T[:, :ns] = T[:, :ns] @ Hh
+        V[:, :ns] = V[:, :ns] @ Hh
+        Th, Qh = hessenberg_blocked(T[:ns, :ns], nb=4)
+        T[:ns, ns:] = Qh.conj().T @ T[:ns, ns:]
+        T[:ns, :ns] = np.triu(Th, -1)
+        V[:, :ns] = V[:, :ns] @ Qh
+    if kw > ilo:
+        H[kw, kw - 1] = s * np.conj(V[0, 0])
+    H[kw:ihi + 1, kw:ihi + 1] = T
+    H[kw:ihi + 1, ihi + 1:] = V.conj().T @ H[kw:ihi + 1, ihi + 1:]
+    H[:kw, kw:ihi + 1] = H[:kw, kw:ihi + 1] @ V
+    Z[:, kw:ihi + 1] = Z[:, kw:ihi + 1] @ V
+    return nd, np.diag(T)[:ns].copy()
+
+
+def multishift_qr_aed(H, Z, ns=4, w=16, nmin=12, nw=None, stats=None, nibble=14):
+    """multishift_qr with an AED step before every sweep."""
+    n = H.shape[0]
+    eps = np.finfo(np.float64).eps
+    nw = nw or (3 * ns) // 2
+    ihi = n - 1
+    sweeps = aeds = 0
+    shift_rows = 0
+    stall = 0
+    while ihi > 0:
+        for i in range(ihi, 0, -1):
+            sc = abs(H[i - 1, i - 1].real) + abs(H[i - 1, i - 1].imag) + abs(H[i, i].real) + abs(H[i, i].imag)
+            if abs(H[i, i - 1].real) + abs(H[i, i - 1].imag) <= eps * (sc if sc else 1.0):
+                H[i, i - 1] = 0.0
+        while ihi > 0 and H[ihi, ihi - 1] == 0:
+            ihi -= 1
+            stall = 0
+        if ihi == 0:
+            break
+        ilo = ihi
+        while ilo > 0 and H[ilo, ilo - 1] != 0:
+            ilo -= 1
+        m = ihi - ilo + 1
+        if m <= nmin:
+            T, U, ok = small_schur(H[ilo:ihi + 1, ilo:ihi + 1])
+            H[ilo:ihi + 1, ilo:ihi + 1] = np.triu(T)
+            H[ilo:ihi + 1, ihi + 1:] = U.conj().T @ H[ilo:ihi + 1, ihi + 1:]
+            H[:ilo, ilo:ihi + 1] = H[:ilo, ilo:ihi + 1] @ U
+            Z[:, ilo:ihi + 1] = Z[:, ilo:ihi + 1] @ U
+            ihi = ilo - 1
+            continue
+        aeds += 1
+        nd, shifts = aed_step(H, Z, ilo, ihi, nw)
+        if nd > 0:
+            stall = 0
+            if nibble is None or nd * 100 >= nibble * min(nw, m):      # enough deflation: skip the sweep, AED again
+                continue
+        stall += 1
+        # recompute active block after AED (ihi may have moved)
+        while ihi > 0 and H[ihi, ihi - 1] == 0:
+            ihi -= 1
+        ilo = ihi
+        while ilo > 0 and H[ilo, ilo - 1] != 0:
+            ilo -= 1
+        m = ihi - ilo + 1
+        if m <= nmin:
+            continue
+        k = min(ns, m // 2, len(shifts))
+        if k < 1:
+            continue
+        # use the k shifts of smallest |.| distance?  LAPACK takes the trailing ones; keep the last k
+        shifts = shifts[-k:]
+        if stall % 6 == 0 and stall > 0:
+            shifts = shifts + 0.75 * abs(H[ihi, ihi - 1]) * np.exp(2j * np.pi * np.arange(k) / k)
+        sweeps += 1
+        shift_rows += k * m
+        tau = 0
+        tau_last = (ihi - 1 - ilo) + 2 * (k - 1)
+        while tau <= tau_last:
+            w0 = max(ilo, ilo + tau - 2 * (k - 1) - 1)
+            w1 = min(w0 + w, ihi + 1)
+            tau_end = tau_last if w1 == ihi + 1 else w1 - 3 - ilo
+            ww = w1 - w0
+            Hw = H[w0:w1, w0:w1].copy()
+            U = np.eye(ww, dtype=np.complex128)
+            for t in range(tau, tau_end + 1):
+                rots = []
+                for s_ in range(k):
+                    p = ilo + t - 2 * s_
+                    if p < ilo or p > ihi - 1:
+                        continue
+                    q = p - w0
+                    if p == ilo:
+                        f, g = Hw[q, q] - shifts[s_], Hw[q + 1, q]
+                    else:
+                        f, g = Hw[q, q - 1], Hw[q + 1, q - 1]
+                    c, sn, r = rotg(f, g)
+                    rots.append((q, c, sn, p == ilo))
+                for (q, c, sn, first) in rots:
+                    G = np.array([[c, sn], [-np.conj(sn), c]])
+                    lo = q if first else q - 1
+                    Hw[q:q + 2, lo:] = G @ Hw[q:q + 2, lo:]
+                    if not first:
+                        Hw[q + 1, q - 1] = 0.0
+                for (q, c, sn, first) in rots:
+                    G = np.array([[c, sn], [-np.conj(sn), c]])
+                    hi = min(q + 2, ww - 1) + 1
+                    Hw[:hi, q:q + 2] = Hw[:hi, q:q + 2] @ G.conj().T
+                    U[:, q:q + 2] = U[:, q:q + 2] @ G.conj().T
+            H[w0:w1, w0:w1] = Hw
+            H[w0:w1, w1:] = U.conj().T @ H[w0:w1, w1:]
+            H[:w0, w0:w1] = H[:w0, w0:w1] @ U
+            Z[:, w0:w1] = Z[:, w0:w1] @ U
+            tau = tau_end + 1
+        if sweeps > 30 * n:
+            return False
+    if stats is not None:
+        stats.update(sweeps=sweeps, aeds=aeds, shift_rows=shift_rows)
+    return True

@@ -95,6 +95,10 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// Ordering point inside a wave: lanes of one wavefront execute in lock-step, so this emits no instruction on gfx950; it
+// stops the compiler from moving LDS accesses across it (and is a rendezvous in the CPU kernel-logic emulator).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Kernels that stage more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in.

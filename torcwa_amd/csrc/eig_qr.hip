@@ -61,6 +61,22 @@ __device__ __forceinline__ void rot_cols(const Rot<T>& R, cx<T>& x, cx<T>& y) {
     x = nx; y = ny;
 }
 
+// Fast rotation generator for the chase (no hypot/divide chain: two rsqrt).  |f|^2+|g|^2 cannot overflow here: the
+// entries of a balanced RCWA operator are O(1e3) and negligible subdiagonals were flushed to zero by the deflation scan.
+template <class T>
+__device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
+    Rot<T> R;
+    const T ag2 = norm2(g), af2 = norm2(f);
+    if (ag2 == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
+    if (af2 == T(0)) { const T ig = rsqrt(ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
+    const T n2 = af2 + ag2;
+    const T u = rsqrt(n2), tt = rsqrt(af2);        // 1/d, 1/|f|
+    R.c = af2 * tt * u;                            // |f| / d
+    R.s = (tt * u) * (f * conj(g));                // (f/|f|) conj(g) / d
+    R.r = (n2 * u * tt) * f;                       // (f/|f|) d
+    return R;
+}
+
 // Single-shift QR (Wilkinson shift) of an m x m (m <= QNMIN) upper Hessenberg matrix held in LDS, executed by ONE
 // wave (blockDim.x == 64).  On return Hs is upper triangular (Schur form); if Us != nullptr it holds U with
 // H_in = U T U^H.  Returns false if it did not converge.
@@ -100,7 +116,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us) {
             cx<T> f, g;
             if (p == l) { f = Hs[l * SLD + l] - sig; g = Hs[(l + 1) * SLD + l]; }
             else { f = Hs[p * SLD + p - 1]; g = Hs[(p + 1) * SLD + p - 1]; }
-            const Rot<T> R = rotg(f, g);
+            const Rot<T> R = rotg_fast(f, g);
             __syncthreads();
             if (lane < 32) {
                 const int lo = (p == l) ? p : p - 1;
@@ -135,6 +151,91 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us) {
     return true;
 }
 
+// Swap the adjacent diagonal entries k, k+1 of the upper-triangular Ts (order m) by one rotation, accumulating into Vs
+// (LAPACK ztrexc for complex Schur forms).  One wave.
+template <class T>
+__device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k) {
+    const int lane = threadIdx.x;
+    const cx<T> a = Ts[k * SLD + k], bq = Ts[(k + 1) * SLD + k + 1], x = Ts[k * SLD + k + 1];
+    const Rot<T> R = rotg_fast(x, bq - a);
+    __syncthreads();
+    if (lane < 32) {
+        const int col = k + lane;
+        if (col < m) {
+            cx<T> u = Ts[k * SLD + col], v = Ts[(k + 1) * SLD + col];
+            rot_rows(R, u, v);
+            Ts[k * SLD + col] = u; Ts[(k + 1) * SLD + col] = v;
+        }
+    } else {
+        const int row = lane - 32;
+        if (row < m) {
+            cx<T> u = Vs[row * SLD + k], v = Vs[row * SLD + k + 1];
+            rot_cols(R, u, v);
+            Vs[row * SLD + k] = u; Vs[row * SLD + k + 1] = v;
+        }
+    }
+    __syncthreads();
+    if (lane <= k + 1) {
+        cx<T> u = Ts[lane * SLD + k], v = Ts[lane * SLD + k + 1];
+        rot_cols(R, u, v);
+        if (lane == k + 1) u = cx<T>(T(0), T(0));
+        Ts[lane * SLD + k] = u; Ts[lane * SLD + k + 1] = v;
+    }
+    __syncthreads();
+}
+
+// Householder reflector for x[0:len] held in LDS at stride `inc` (LAPACK zlarfg): H = I - tau v v^H, H^H x = beta e1.
+// All lanes compute redundantly; v (v[0] = 1) is written to vw[0:len] by the lanes; returns tau, beta.
+template <class T>
+__device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& tau, T& beta) {
+    const int lane = threadIdx.x;
+    const cx<T> alpha = x[0];
+    T xn2 = T(0);
+    for (int i = 1; i < len; ++i) xn2 += norm2(x[i * inc]);
+    cx<T> scale;
+    if (xn2 == T(0) && alpha.y == T(0)) {
+        tau = cx<T>(T(0), T(0)); beta = alpha.x; scale = cx<T>(T(0), T(0));
+    } else {
+        const T nrm = sqrt(norm2(alpha) + xn2);
+        beta = (alpha.x >= T(0)) ? -nrm : nrm;
+        tau = cx<T>((beta - alpha.x) / beta, -alpha.y / beta);
+        scale = crecip(cx<T>(alpha.x - beta, alpha.y));
+    }
+    __syncthreads();
+    if (lane < len) vw[lane] = (lane == 0) ? cx<T>(T(1), T(0)) : x[lane * inc] * scale;
+    __syncthreads();
+}
+
+// Apply H = I - tau v v^H (v on rows/cols [o, o+len)) to the m x m Ts from both sides (Ts <- H^H Ts H, left side on
+// columns >= c0) and to Vs from the right.  One wave: lanes 0..31 own a column (left) / a row of Ts (right), lanes
+// 32..63 a row of Vs.
+template <class T>
+__device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, int o, int len, int c0, const cx<T>* vw, cx<T> tau) {
+    const int lane = threadIdx.x;
+    if (lane < 32) {
+        const int c = lane;
+        if (c >= c0 && c < m) {
+            cx<T> w(T(0), T(0));
+            for (int i = 0; i < len; ++i) cfma_conj(w, vw[i], Ts[(o + i) * SLD + c]);
+            const cx<T> f = conj(tau) * w;
+            for (int i = 0; i < len; ++i) Ts[(o + i) * SLD + c] -= vw[i] * f;
+        }
+    }
+    __syncthreads();
+    {
+        cx<T>* Mx = (lane < 32) ? Ts : Vs;
+        const int r = (lane < 32) ? lane : lane - 32;
+        const int lim = (lane < 32) ? nrows_t : m;
+        if (r < lim) {
+            cx<T> w(T(0), T(0));
+            for (int i = 0; i < len; ++i) cfma(w, Mx[r * SLD + o + i], vw[i]);
+            const cx<T> f = tau * w;
+            for (int i = 0; i < len; ++i) Mx[r * SLD + o + i] -= f * conj(vw[i]);
+        }
+    }
+    __syncthreads();
+}
+
 template <class T>
 __global__ __launch_bounds__(64) void qr_init_kernel(QrState* __restrict__ st, int n) {
     if (threadIdx.x == 0) {
@@ -151,6 +252,8 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
                                                         int* __restrict__ summary, int max_sweeps) {
     __shared__ cx<T> Hs[QNMIN * SLD];
     __shared__ cx<T> Us[QNMIN * SLD];
+    __shared__ cx<T> vwork[QNMIN];
+    __shared__ cx<T> wk[QNMIN];
     __shared__ QrState sst;
     const int b = blockIdx.x, lane = threadIdx.x;
     cx<T>* H = Aall + (long)b * n * n;
@@ -219,42 +322,103 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         }
         return;
     }
-    // chase mode: shifts from the trailing k x k block
+    // ---- aggressive early deflation on the trailing nw x nw window (Braman/Byers/Mathias; LAPACK zlaqr3) ----------
     if (st.sweeps >= max_sweeps) {
         if (lane == 0) { st.fail += ihi + 1; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
         return;
     }
-    const int k = (m / 2 < QNS) ? m / 2 : QNS;
-    const int o = ihi - k + 1;
-    for (int e = lane; e < k * k; e += 64) {
-        const int r = e / k, c = e - r * k;
-        Hs[r * SLD + c] = (r <= c + 1) ? H[(long)(o + r) * n + o + c] : cx<T>(T(0), T(0));
+    const int nw = QNMIN;                       // m > QNMIN here, so the window is strictly inside the active block
+    const int kw = ihi - nw + 1;
+    cx<T> spike = H[(long)kw * n + kw - 1];
+    for (int e = lane; e < nw * nw; e += 64) {
+        const int r = e / nw, c = e - r * nw;
+        Hs[r * SLD + c] = (r <= c + 1) ? H[(long)(kw + r) * n + kw + c] : cx<T>(T(0), T(0));
+        Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
     }
     __syncthreads();
-    small_schur<T>(Hs, k, (cx<T>*)nullptr);
+    const bool okw = small_schur<T>(Hs, nw, Us);
     __syncthreads();
-    cx<T>* sh = shifts_all + (long)b * QNS;
-    if (lane < k) {
-        cx<T> s = Hs[lane * SLD + lane];
-        if (st.stall > 0 && (st.stall % 6) == 0) {
-            const T mag = T(0.75) * cabs(H[(long)ihi * n + ihi - 1]);
-            T sn, cs;
-            const T ang = T(6.283185307179586) * (T)lane / (T)k;
-            sn = sin(ang); cs = cos(ang);
-            s = s + cx<T>(mag * cs, mag * sn);
+    int ns = nw;
+    if (okw) {
+        const T smlnum = eps_of<T>::safmin * ((T)n / ulp);
+        int ilst = 0;
+        while (ilst < ns) {
+            T foo = abs1(Hs[(ns - 1) * SLD + ns - 1]);
+            if (foo == T(0)) foo = abs1(spike);
+            const T sp = abs1(spike) * abs1(Us[ns - 1]);            // |s| |V[0, ns-1]|
+            const T thr = (smlnum > ulp * foo) ? smlnum : ulp * foo;
+            if (sp <= thr) {
+                --ns;                                                // deflatable
+            } else {
+                for (int kk = ns - 2; kk >= ilst; --kk) schur_swap<T>(Hs, Us, nw, kk);
+                ++ilst;
+            }
         }
-        sh[lane] = s;
     }
-    if (lane == 0) {
-        st.k = k; st.tau = 0; st.tau_last = (ihi - 1 - ilo) + 2 * (k - 1); st.mode = QR_CHASE;
-        st.stall += 1; st.sweeps += 1; st.w0 = st.w1 = 0;
-        stall_[b] = st;
-        atomicAdd(&summary[0], 1);
-        atomicMax(&summary[1], m);
+    const int nd = nw - ns;
+    cx<T>* sh = shifts_all + (long)b * QNS;
+    if (nd == 0) {
+        // nothing deflates: H is untouched; the window's eigenvalues (bottom k of them) are the shifts of a full sweep
+        const int k = (m / 2 < QNS) ? m / 2 : QNS;
+        if (lane < k) {
+            cx<T> sv = Hs[(nw - k + lane) * SLD + nw - k + lane];
+            if (st.stall > 0 && (st.stall % 6) == 0) {
+                const T mag = T(0.75) * cabs(H[(long)ihi * n + ihi - 1]);
+                const T ang = T(6.283185307179586) * (T)lane / (T)k;
+                sv = sv + cx<T>(mag * (T)cos(ang), mag * (T)sin(ang));
+            }
+            sh[lane] = sv;
+        }
+        if (lane == 0) {
+            st.k = k; st.tau = 0; st.tau_last = (ihi - 1 - ilo) + 2 * (k - 1); st.mode = QR_CHASE;
+            st.stall += 1; st.sweeps += 1; st.w0 = st.w1 = 0;
+            stall_[b] = st;
+            atomicAdd(&summary[0], 1);
+            atomicMax(&summary[1], m);
+        }
+        return;
+    }
+    // nd > 0: commit the window in Schur/Hessenberg form and publish V for the off-window update
+    if (ns == 0) spike = cx<T>(T(0), T(0));
+    if (ns > 1 && (spike.x != T(0) || spike.y != T(0))) {
+        // reflector that maps the spike s*conj(V[0,0:ns]) onto e1, then return T[0:ns,0:ns] to Hessenberg form
+        cx<T>* vw = vwork;
+        if (lane < ns) wk[lane] = conj(Us[lane]);
+        __syncthreads();
+        cx<T> tau; T beta;
+        small_larfg<T>(wk, 1, ns, vw, tau, beta);
+        small_apply_reflector<T>(Hs, Us, nw, ns, 0, ns, 0, vw, tau);
+        for (int jc = 0; jc + 2 < ns; ++jc) {
+            small_larfg<T>(Hs + (jc + 1) * SLD + jc, SLD, ns - jc - 1, vw, tau, beta);
+            if (lane == 0) Hs[(jc + 1) * SLD + jc] = cx<T>(beta, T(0));
+            if (lane >= 1 && lane < ns - jc - 1) Hs[(jc + 1 + lane) * SLD + jc] = cx<T>(T(0), T(0));
+            __syncthreads();
+            small_apply_reflector<T>(Hs, Us, nw, ns, jc + 1, ns - jc - 1, jc + 1, vw, tau);
+        }
+    }
+    __syncthreads();
+    {
+        cx<T>* U = Uall + (long)b * QW * QW;
+        for (int e = lane; e < nw * nw; e += 64) {
+            const int r = e / nw, c = e - r * nw;
+            cx<T> v = Hs[r * SLD + c];
+            if (r > c + 1 || (r == c + 1 && r >= ns)) v = cx<T>(T(0), T(0));
+            H[(long)(kw + r) * n + kw + c] = v;
+            U[r * QW + c] = Us[r * SLD + c];
+        }
+        if (lane == 0) {
+            H[(long)kw * n + kw - 1] = spike * conj(Us[0]);
+            st.w0 = kw; st.w1 = ihi + 1; st.mode = QR_SMALL_PENDING; st.stall = 0;
+            stall_[b] = st;
+            atomicAdd(&summary[0], 1);
+            atomicOr(&summary[2], 1);
+        }
     }
 }
 
-// One window step of the bulge chain.
+// One window step of the bulge chain.  Thread layout: 16 groups of 16 lanes, group s owns bulge s: its lanes
+// compute the rotation redundantly (no broadcast barrier), then stride over the window's columns (left rotation)
+// and, after one barrier, over its rows and the rows of U (right rotation).  Two barriers per chain step.
 template <class T>
 __global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all) {
@@ -262,10 +426,7 @@ __global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
     cx<T>* Uw = Hw + QW * LD;                          // [QW][LD]
-    Rot<T>* rots = reinterpret_cast<Rot<T>*>(Uw + QW * LD);   // [QNS]   (all LDS lives in the dynamic region)
-    int* rq = reinterpret_cast<int*>(rots + QNS);      // [QNS] window-local position, -1 = inactive
-    int* rfirst = rq + QNS;                            // [QNS]
-    QrState& sst = *reinterpret_cast<QrState*>(rfirst + QNS);
+    QrState& sst = *reinterpret_cast<QrState*>(Uw + QW * LD);
     const int b = blockIdx.x, t = threadIdx.x;
     if (t == 0) sst = st_all[b];
     __syncthreads();
@@ -283,68 +444,65 @@ __global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall
     if (w1 > ihi + 1) w1 = ihi + 1;
     const int ww = w1 - w0;
     const int tau_end = (w1 == ihi + 1) ? st.tau_last : (w1 - 3 - ilo);
-    for (int e = t; e < ww * ww; e += 256) {
-        const int r = e / ww, c = e - r * ww;
-        Hw[r * LD + c] = H[(long)(w0 + r) * n + w0 + c];
-        Uw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+    {
+        const int c = t & 63, r4 = t >> 6;
+        for (int r = r4; r < ww; r += 4) {
+            if (c < ww) {
+                Hw[r * LD + c] = H[(long)(w0 + r) * n + w0 + c];
+                Uw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+            }
+        }
     }
-    const cx<T>* sh = shifts_all + (long)b * QNS;
+    const int sb = t >> 4, j = t & 15;               // bulge index, lane within the group
+    const cx<T> shift = (sb < k) ? shifts_all[(long)b * QNS + sb] : cx<T>(T(0), T(0));
     __syncthreads();
     for (int tau = st.tau; tau <= tau_end; ++tau) {
-        if (t < QNS) {
-            int q = -1, first = 0;
-            if (t < k) {
-                const int p = ilo + tau - 2 * t;
-                if (p >= ilo && p <= ihi - 1) {
-                    q = p - w0;
-                    cx<T> f, g;
-                    if (p == ilo) { first = 1; f = Hw[q * LD + q] - sh[t]; g = Hw[(q + 1) * LD + q]; }
-                    else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
-                    rots[t] = rotg(f, g);
-                }
+        const int p = ilo + tau - 2 * sb;
+        const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
+        const int q = p - w0;
+        const bool first = (p == ilo);
+        Rot<T> R;
+        if (active) {
+            cx<T> f, g;
+            if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
+            else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
+            R = rotg_fast(f, g);
+        }
+        wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
+        if (active) {
+            const int lo = first ? q : q - 1;
+            for (int col = lo + j; col < ww; col += 16) {
+                cx<T> x = Hw[q * LD + col], y = Hw[(q + 1) * LD + col];
+                rot_rows(R, x, y);
+                if (!first && col == q - 1) { x = R.r; y = cx<T>(T(0), T(0)); }
+                Hw[q * LD + col] = x; Hw[(q + 1) * LD + col] = y;
             }
-            rq[t] = q; rfirst[t] = first;
         }
         __syncthreads();
-        // left rotations: rows q, q+1 over the window's columns
-        for (int e = t; e < k * ww; e += 256) {
-            const int s = e / ww, col = e - s * ww;
-            const int q = rq[s];
-            if (q < 0) continue;
-            const int lo = rfirst[s] ? q : q - 1;
-            if (col < lo) continue;
-            cx<T> x = Hw[q * LD + col], y = Hw[(q + 1) * LD + col];
-            rot_rows(rots[s], x, y);
-            if (!rfirst[s] && col == q - 1) { x = rots[s].r; y = cx<T>(T(0), T(0)); }
-            Hw[q * LD + col] = x; Hw[(q + 1) * LD + col] = y;
-        }
-        __syncthreads();
-        // right rotations: columns q, q+1 of the window rows 0..min(q+2, ww-1), and of U (all rows)
-        for (int e = t; e < 2 * k * ww; e += 256) {
-            const int half = e / (k * ww);
-            const int e2 = e - half * k * ww;
-            const int s = e2 / ww, row = e2 - s * ww;
-            const int q = rq[s];
-            if (q < 0) continue;
-            if (half == 0) {
-                const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
-                if (row > hi) continue;
+        if (active) {
+            const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
+            for (int row = j; row <= hi; row += 16) {
                 cx<T> x = Hw[row * LD + q], y = Hw[row * LD + q + 1];
-                rot_cols(rots[s], x, y);
+                rot_cols(R, x, y);
                 Hw[row * LD + q] = x; Hw[row * LD + q + 1] = y;
-            } else {
+            }
+            for (int row = j; row < ww; row += 16) {
                 cx<T> x = Uw[row * LD + q], y = Uw[row * LD + q + 1];
-                rot_cols(rots[s], x, y);
+                rot_cols(R, x, y);
                 Uw[row * LD + q] = x; Uw[row * LD + q + 1] = y;
             }
         }
         __syncthreads();
     }
     cx<T>* U = Uall + (long)b * QW * QW;
-    for (int e = t; e < ww * ww; e += 256) {
-        const int r = e / ww, c = e - r * ww;
-        H[(long)(w0 + r) * n + w0 + c] = Hw[r * LD + c];
-        U[r * QW + c] = Uw[r * LD + c];
+    {
+        const int c = t & 63, r4 = t >> 6;
+        for (int r = r4; r < ww; r += 4) {
+            if (c < ww) {
+                H[(long)(w0 + r) * n + w0 + c] = Hw[r * LD + c];
+                U[r * QW + c] = Uw[r * LD + c];
+            }
+        }
     }
     if (t == 0) { st_all[b].tau = tau_end + 1; st_all[b].w0 = w0; st_all[b].w1 = w1; }
 }
@@ -481,7 +639,7 @@ template <class T>
 int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info) {
     constexpr int LD = QW + 1;
     const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
-    const size_t smw = sm2 + sizeof(Rot<T>) * QNS + sizeof(int) * 2 * QNS + sizeof(QrState);
+    const size_t smw = sm2 + sizeof(QrState);
     const size_t sma = sizeof(T) * 4 * APLANE;
     if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_left_kernel<T>, sma) ||
         set_max_dyn_smem((const void*)apply_right_kernel<T>, sma))
