@@ -35,10 +35,10 @@ def make_inputs(batch, order, device, rank, seed_shift=0):
     return freq, grids.contiguous(), lam_b
 
 
-def run_step(freq, grids, order, engine, precision, chunk):
+def run_step(freq, grids, order, engine, precision, chunk, streams):
     from torcwa_amd.sweep import solve_single_layer_sweep
     return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
-                                    precision=precision, engine=engine, chunk=chunk, check_info=False)
+                                    precision=precision, engine=engine, chunk=chunk, streams=streams, check_info=False)
 
 
 def cpu_baseline(order, lam_nm, eps_si, threads):
@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sweep points per step per GPU")
     ap.add_argument("--order", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=0, help="points solved concurrently (0 = whole batch)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -121,7 +122,7 @@ def main():
     engine = torcwa_amd.Engine(device=device)
     order = [args.order, args.order]
     n = 2 * (2 * args.order + 1) ** 2
-    chunk = args.chunk if args.chunk > 0 else args.batch
+    chunk = args.chunk if args.chunk > 0 else -(-args.batch // max(1, args.streams))
     freq, grids, lam_b = make_inputs(args.batch, order, device, rank)
 
     def barrier():
@@ -131,14 +132,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        out = run_step(freq, grids, order, engine, args.precision, chunk)
+        out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
     barrier()
     # HIP-event timing of the dominant kernels, recorded by libtrx on the launch stream during the timed region
     engine.lib.prof_reset()
     engine.lib.prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_step(freq, grids, order, engine, args.precision, chunk)
+        out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
     barrier()
     elapsed = time.perf_counter() - t0
     engine.lib.prof_enable(0)
@@ -161,7 +162,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: single patterned layer, order=[%d,%d] (n=%d), 300x300 grid, %d-lambda sweep per GPU, "
                                    "glass input half-space" % (args.order, args.order, n, args.batch),
-                       "batch_per_gpu": args.batch, "chunk": chunk, "precision": args.precision},
+                       "batch_per_gpu": args.batch, "chunk": chunk, "streams": args.streams, "precision": args.precision},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)],
         }
         res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed)

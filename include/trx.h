@@ -95,6 +95,19 @@ size_t trx_redheffer_ws_bytes(int dtype, int n, int batch);
 int trx_redheffer(int dtype, const void* const* Sm, const void* const* Sn, void* const* Sout, void* XY, int n, int batch,
                   int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
 
+/* Star product with a HALF-SPACE operand (the Sin / Sout coupling steps of solve_global_smatrix, rcwa.py:198-208).
+ * The four blocks of Sin / Sout are 2x2-block-diagonal (rcwa.py:1157-1181), so they are passed as diagonals
+ * bd[4 blocks S11,S21,S12,S22][4 diagonals d11,d12,d21,d22][batch][N] and every product with them is O(n^2).
+ * side = 0: half-space on the left (Sin * S);  side = 1: on the right (S * Sout).  Other arguments as trx_redheffer. */
+int trx_redheffer_halfspace(int dtype, int side, const void* bd, const void* const* S, void* const* Sout, void* XY, int N, int batch,
+                            int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
+
+/* A = P Q (rcwa.py:1236) for a layer with homogeneous mu[batch], from its block structure (two N^3 GEMMs instead of
+ * one (2N)^3): A = [[mu E - Ky^2 - Kx Gx, KxKy - Kx Gy],[KxKy - Ky Gx, mu E - Kx^2 - Ky Gy]], G* = Einv (K* E). */
+size_t trx_build_a_ws_bytes(int dtype, int N, int batch);
+int trx_build_a(int dtype, const void* E, const void* Einv, const void* mu, const void* kx, const void* ky, int N, int batch, void* A,
+                void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart): HIP-event timing of the dominant kernels --------------------
  * trx_prof_enable(1) makes the instrumented launch sites record hipEvents on the launch stream (pool of 4096 per
  * tag; launches beyond the pool are counted but not timed).  trx_prof_get(tag, out[6]) waits for those events and

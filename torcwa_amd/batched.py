@@ -205,7 +205,8 @@ class BatchedRCWA:
             if Minv is None:
                 Minv = eng.inverse(M)
             P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
-            A = eng.gemm(P, Q)
+            # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
+            A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
             lam, W = eng.eig(A, destroy=True)                                           # torch_eig.py:14
             del A
             kz = torch.sqrt(lam)
@@ -267,6 +268,22 @@ class BatchedRCWA:
             C[1].append(Cn[1][k] + eng.gemm(Cn[0][k], X2.contiguous()))
         return S, C
 
+    def _RS_halfspace(self, side, Sbd, S, C):
+        """Star product with Sin (side 0) / Sout (side 1), whose blocks are 2x2-block-diagonal: O(n^2) products with them."""
+        eng = self.engine
+        bd = torch.stack([torch.stack(blk.d, dim=0) for blk in Sbd], dim=0).to(self._cdtype).contiguous()   # [4,4,B,N]
+        Sn, X1, X2, Y1, Y2 = eng.redheffer_halfspace(side, bd, S)
+        Cn = [[], []]
+        if side == 0:                       # C belongs to the right operand (rcwa.py:1302-1304)
+            for k in range(len(C[0])):
+                Cn[0].append(eng.gemm(C[0][k], X1.contiguous()))
+                Cn[1].append(C[1][k] + eng.gemm(C[0][k], X2.contiguous()))
+        else:                               # C belongs to the left operand (rcwa.py:1298-1300)
+            for m in range(len(C[0])):
+                Cn[0].append(C[0][m] + eng.gemm(C[1][m], Y1.contiguous()))
+                Cn[1].append(eng.gemm(C[1][m], Y2.contiguous()))
+        return Sn, Cn
+
     def _layer_S(self, i):
         # the layer S-matrix is symmetric under port exchange: S22 = S11, S12 = S21 (SURVEY.md section 7.2)
         return [self.layer_S11[i], self.layer_S21[i], self.layer_S21[i], self.layer_S11[i]]
@@ -290,10 +307,10 @@ class BatchedRCWA:
             self._zero_layer_S = not (self.has_in or self.has_out)     # reference stores 1-D zeros (rcwa.py:187-188)
         for i in range(1, self.layer_N):
             S, C = self._RS_prod(S, self._layer_S(i), C, self._layer_C(i))
-        if self.has_in:
-            S, C = self._RS_prod([b.dense() for b in self._Sin], S, [[], []], C)
-        if self.has_out:
-            S, C = self._RS_prod(S, [b.dense() for b in self._Sout], C, [[], []])
+        if self.has_in:                                                                 # rcwa.py:198-202
+            S, C = self._RS_halfspace(0, self._Sin, S, C)
+        if self.has_out:                                                                # rcwa.py:204-208
+            S, C = self._RS_halfspace(1, self._Sout, S, C)
         self.S = S
         self.C = C
 

@@ -44,27 +44,27 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(int m, int n, int k, cx<
     constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDM;
 
     cx<T> ra[4], rb[4];
+    // Branch-free tile loads: out-of-range coordinates are clamped to a valid address and the value is zeroed by a
+    // select, so the 8 global_load_dwordx4 of a slab issue back-to-back instead of each sitting in its own exec branch.
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = t + 256 * r;
             {
                 const int row = A_KC ? (e >> 4) : (e & 63), kk = A_KC ? (e & 15) : (e >> 6);
-                cx<T> v(T(0), T(0));
-                if (m0 + row < m && k0 + kk < k) {
-                    if (OPA == TRX_OP_N) v = A[(long)(m0 + row) * lda + k0 + kk];
-                    else { v = A[(long)(k0 + kk) * lda + m0 + row]; if (OPA == TRX_OP_C) v = conj(v); }
-                }
-                ra[r] = v;
+                const bool ok = (m0 + row < m) && (k0 + kk < k);
+                const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
+                cx<T> v = (OPA == TRX_OP_N) ? A[(long)gr * lda + gk] : A[(long)gk * lda + gr];
+                if (OPA == TRX_OP_C) v.y = -v.y;
+                ra[r] = ok ? v : cx<T>(T(0), T(0));
             }
             {
                 const int col = B_KC ? (e >> 4) : (e & 63), kk = B_KC ? (e & 15) : (e >> 6);
-                cx<T> v(T(0), T(0));
-                if (n0 + col < n && k0 + kk < k) {
-                    if (OPB == TRX_OP_N) v = B[(long)(k0 + kk) * ldb + n0 + col];
-                    else { v = B[(long)(n0 + col) * ldb + k0 + kk]; if (OPB == TRX_OP_C) v = conj(v); }
-                }
-                rb[r] = v;
+                const bool ok = (n0 + col < n) && (k0 + kk < k);
+                const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
+                cx<T> v = (OPB == TRX_OP_N) ? B[(long)gk * ldb + gc] : B[(long)gc * ldb + gk];
+                if (OPB == TRX_OP_C) v.y = -v.y;
+                rb[r] = ok ? v : cx<T>(T(0), T(0));
             }
         }
     };
@@ -130,6 +130,7 @@ template <class T>
 int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
          const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc) {
     if (m <= 0 || n <= 0 || batch <= 0) return TRX_OK;
+    if (k <= 0 && !desc) return TRX_ERR_ARG;          // callers never pass an empty inner dimension
     dim3 grid(cdiv_i(n, BN), cdiv_i(m, BM), batch);
     // algorithmic work of this launch: 8 real flops per complex MAC; bytes = A + B read once, C written (+read if beta)
     const double macs = (double)m * n * k * batch;

@@ -46,15 +46,21 @@ __device__ __forceinline__ void cmma_tile_strided(const T* __restrict__ Ar, cons
         const T ar = Ar[aoff + k0 * sAk];
         const T ai = Ai[aoff + k0 * sAk];
         const T nai = -ai;
+        T br[NT], bi[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const T br = Br[boff + k0 * sBk + 16 * j * sBc];
-            const T bi = Bi[boff + k0 * sBk + 16 * j * sBc];
-            accR[j] = Mfma<T>::mma(ar, br, accR[j]);
-            accR[j] = Mfma<T>::mma(nai, bi, accR[j]);
-            accI[j] = Mfma<T>::mma(ar, bi, accI[j]);
-            accI[j] = Mfma<T>::mma(ai, br, accI[j]);
+            br[j] = Br[boff + k0 * sBk + 16 * j * sBc];
+            bi[j] = Bi[boff + k0 * sBk + 16 * j * sBc];
         }
+        // issue order keeps 2*NT independent MFMAs between two updates of the same accumulator
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accR[j] = Mfma<T>::mma(ar, br[j], accR[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accI[j] = Mfma<T>::mma(ar, bi[j], accI[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accR[j] = Mfma<T>::mma(nai, bi[j], accR[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accI[j] = Mfma<T>::mma(ai, br[j], accI[j]);
     }
 }
 

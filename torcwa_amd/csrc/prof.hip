@@ -1,5 +1,6 @@
 #include "prof.hpp"
 
+#include <mutex>
 #include <vector>
 
 namespace trx {
@@ -13,12 +14,14 @@ struct TagData {
 };
 TagData g_tags[PROF_NTAGS];
 bool g_on = false;
+std::mutex g_mu;
 constexpr int POOL = 4096;
 }  // namespace
 
 bool prof_enabled() { return g_on; }
 
 int prof_begin(int tag, hipStream_t s, double flops, double bytes) {
+    std::lock_guard<std::mutex> lock(g_mu);
     TagData& t = g_tags[tag];
     t.launches += 1;
     t.flops += flops;
@@ -37,7 +40,10 @@ int prof_begin(int tag, hipStream_t s, double flops, double bytes) {
     return slot;
 }
 
-void prof_end(int tag, int slot, hipStream_t s) { hipEventRecord(g_tags[tag].stop[slot], s); }
+void prof_end(int tag, int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    hipEventRecord(g_tags[tag].stop[slot], s);
+}
 }  // namespace trx
 
 using namespace trx;

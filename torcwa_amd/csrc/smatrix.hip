@@ -197,6 +197,158 @@ int redheffer_t(hipStream_t s, const cx<T>* const* Sm, const cx<T>* const* Sn, c
     return TRX_OK;
 }
 
+
+// ---- 2x2-block-diagonal operators (Sin/Sout blocks, rcwa.py:1157-1181): D = [[d0, d1], [d2, d3]], each d* a diagonal ----
+// out = alpha * (D X) [+ I] [+ Y]     (row combination: rows i and i+N of X)
+template <class T>
+__global__ __launch_bounds__(256) void bd_rowcomb_kernel(const cx<T>* __restrict__ d, long dstride, const cx<T>* __restrict__ X, int ldx, long sx,
+                                                         const cx<T>* __restrict__ Y, int ldy, long sy, cx<T>* __restrict__ out, int ldo, long so,
+                                                         int N, int ncols, T alpha, int add_identity) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    const long di = (long)b * N + i;
+    const cx<T> d0 = d[di], d1 = d[dstride + di], d2 = d[2 * dstride + di], d3 = d[3 * dstride + di];
+    const cx<T> x0 = X[(long)b * sx + (long)i * ldx + j], x1 = X[(long)b * sx + (long)(i + N) * ldx + j];
+    cx<T> o0 = alpha * (d0 * x0 + d1 * x1), o1 = alpha * (d2 * x0 + d3 * x1);
+    if (add_identity) { if (j == i) o0.x += T(1); if (j == i + N) o1.x += T(1); }
+    if (Y) { o0 += Y[(long)b * sy + (long)i * ldy + j]; o1 += Y[(long)b * sy + (long)(i + N) * ldy + j]; }
+    out[(long)b * so + (long)i * ldo + j] = o0;
+    out[(long)b * so + (long)(i + N) * ldo + j] = o1;
+}
+// out = alpha * (X D) [+ I]           (column combination: columns j and j+N of X)
+template <class T>
+__global__ __launch_bounds__(256) void bd_colcomb_kernel(const cx<T>* __restrict__ d, long dstride, const cx<T>* __restrict__ X, int ldx, long sx,
+                                                         cx<T>* __restrict__ out, int ldo, long so, int N, int nrows, T alpha, int add_identity) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;      // j in [0, N)
+    if (j >= N || i >= nrows) return;
+    const long dj = (long)b * N + j;
+    const cx<T> d0 = d[dj], d1 = d[dstride + dj], d2 = d[2 * dstride + dj], d3 = d[3 * dstride + dj];
+    const cx<T> x0 = X[(long)b * sx + (long)i * ldx + j], x1 = X[(long)b * sx + (long)i * ldx + j + N];
+    cx<T> o0 = alpha * (x0 * d0 + x1 * d2), o1 = alpha * (x0 * d1 + x1 * d3);
+    if (add_identity) { if (i == j) o0.x += T(1); if (i == j + N) o1.x += T(1); }
+    out[(long)b * so + (long)i * ldo + j] = o0;
+    out[(long)b * so + (long)i * ldo + j + N] = o1;
+}
+// out = dense(D) [+ Y]
+template <class T>
+__global__ __launch_bounds__(256) void bd_dense_kernel(const cx<T>* __restrict__ d, long dstride, const cx<T>* __restrict__ Y, int ldy, long sy,
+                                                       cx<T>* __restrict__ out, int ldo, long so, int N) {
+    const int b = blockIdx.z, i = blockIdx.y;                 // i in [0, 2N)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 2 * N;
+    if (j >= n) return;
+    cx<T> v(T(0), T(0));
+    const int ii = i < N ? i : i - N, jj = j < N ? j : j - N;
+    if (ii == jj) v = d[(long)((i < N ? 0 : 2) + (j < N ? 0 : 1)) * dstride + (long)b * N + ii];
+    if (Y) v += Y[(long)b * sy + (long)i * ldy + j];
+    out[(long)b * so + (long)i * ldo + j] = v;
+}
+
+// Star product with a HALF-SPACE operand whose four blocks are 2x2-block-diagonal (Sin on the left, side = 0, or
+// Sout on the right, side = 1): every product with a block-diagonal factor is an O(n^2) row/column combination.
+// bd: [4 blocks (S11,S21,S12,S22)][4 diagonals][B][N].
+template <class T>
+int redheffer_halfspace_t(hipStream_t s, int side, const cx<T>* bd, const cx<T>* const* S, cx<T>* const* O, cx<T>* XY, int N, int batch,
+                          int* piv, int* info, cx<T>* ws) {
+    const int n = 2 * N;
+    const long nn = (long)n * n, bn = (long)batch * nn, bN = (long)batch * N;
+    const cx<T> one(T(1), T(0)), zero(T(0), T(0));
+    const dim3 blk(256), gN(cdiv_i(n, 256), N, batch), gn(cdiv_i(n, 256), n, batch), gc(cdiv_i(N, 256), n, batch);
+    const cx<T>*D11 = bd, *D21 = bd + 4 * bN, *D12 = bd + 8 * bN, *D22 = bd + 12 * bN;
+    cx<T>* K = ws;                 // [B,n,n]
+    cx<T>* X = XY;                 // [B,n,2n]  X1 | X2
+    cx<T>* Y = XY + 2 * bn;        // [B,n,2n]  Y1 | Y2
+    int rc;
+    if (side == 0) {
+        // Sm = half-space (block diagonal), Sn = S (dense)
+        // K = I - Sm12 Sn21 ;  RHS = [Sm11 | Sm12 Sn22]
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[1], n, nn, (const cx<T>*)nullptr, 0, 0L, K, n, nn, N, n, T(-1), 1);
+        TRX_LAUNCH((bd_dense_kernel<T>), gn, blk, 0, s, D11, bN, (const cx<T>*)nullptr, 0, 0L, X, 2 * n, 2 * nn, N);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[3], n, nn, (const cx<T>*)nullptr, 0, 0L, X + n, 2 * n, 2 * nn, N, n, T(1), 0);
+        rc = lu_factor<T>(s, K, n, nn, n, piv, batch, info); if (rc) return rc;
+        rc = lu_solve<T>(s, K, n, nn, n, piv, X, 2 * n, 2 * nn, 2 * n, batch); if (rc) return rc;
+        // S11 = Sn11 X1 ; S12 = Sn12 + Sn11 X2 ; Y1 = Sn21 X1 ; Y2 = Sn22 + Sn21 X2
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[0], n, nn, X, 2 * n, 2 * nn, zero, O[0], n, nn, batch); if (rc) return rc;
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[2], n, nn, O[2], n, nn, n, n, T(1), 0);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[0], n, nn, X + n, 2 * n, 2 * nn, one, O[2], n, nn, batch); if (rc) return rc;
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[1], n, nn, X, 2 * n, 2 * nn, zero, Y, 2 * n, 2 * nn, batch); if (rc) return rc;
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[3], n, nn, Y + n, 2 * n, 2 * nn, n, n, T(1), 0);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[1], n, nn, X + n, 2 * n, 2 * nn, one, Y + n, 2 * n, 2 * nn, batch); if (rc) return rc;
+        // S21 = Sm21 + Sm22 Y1 ; S22 = Sm22 Y2          (row combinations)
+        TRX_LAUNCH((bd_dense_kernel<T>), gn, blk, 0, s, D21, bN, (const cx<T>*)nullptr, 0, 0L, O[1], n, nn, N);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D22, bN, (const cx<T>*)Y, 2 * n, 2 * nn, (const cx<T>*)O[1], n, nn, O[1], n, nn, N, n, T(1), 0);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D22, bN, (const cx<T>*)(Y + n), 2 * n, 2 * nn, (const cx<T>*)nullptr, 0, 0L, O[3], n, nn, N, n, T(1), 0);
+    } else {
+        // Sm = S (dense), Sn = half-space (block diagonal)
+        // K = I - Sm12 Sn21 (column combination) ;  RHS = [Sm11 | Sm12 Sn22]
+        TRX_LAUNCH((bd_colcomb_kernel<T>), gc, blk, 0, s, D21, bN, S[2], n, nn, K, n, nn, N, n, T(-1), 1);
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[0], n, nn, X, 2 * n, 2 * nn, n, n, T(1), 0);
+        TRX_LAUNCH((bd_colcomb_kernel<T>), gc, blk, 0, s, D22, bN, S[2], n, nn, X + n, 2 * n, 2 * nn, N, n, T(1), 0);
+        rc = lu_factor<T>(s, K, n, nn, n, piv, batch, info); if (rc) return rc;
+        rc = lu_solve<T>(s, K, n, nn, n, piv, X, 2 * n, 2 * nn, 2 * n, batch); if (rc) return rc;
+        // S11 = Sn11 X1 ; S12 = Sn12 + Sn11 X2 ; Y1 = Sn21 X1 ; Y2 = Sn22 + Sn21 X2   (all row combinations)
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D11, bN, (const cx<T>*)X, 2 * n, 2 * nn, (const cx<T>*)nullptr, 0, 0L, O[0], n, nn, N, n, T(1), 0);
+        TRX_LAUNCH((bd_dense_kernel<T>), gn, blk, 0, s, D12, bN, (const cx<T>*)nullptr, 0, 0L, O[2], n, nn, N);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D11, bN, (const cx<T>*)(X + n), 2 * n, 2 * nn, (const cx<T>*)O[2], n, nn, O[2], n, nn, N, n, T(1), 0);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D21, bN, (const cx<T>*)X, 2 * n, 2 * nn, (const cx<T>*)nullptr, 0, 0L, Y, 2 * n, 2 * nn, N, n, T(1), 0);
+        TRX_LAUNCH((bd_dense_kernel<T>), gn, blk, 0, s, D22, bN, (const cx<T>*)nullptr, 0, 0L, Y + n, 2 * n, 2 * nn, N);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D21, bN, (const cx<T>*)(X + n), 2 * n, 2 * nn, (const cx<T>*)(Y + n), 2 * n, 2 * nn, Y + n, 2 * n, 2 * nn, N, n, T(1), 0);
+        // S21 = Sm21 + Sm22 Y1 ; S22 = Sm22 Y2
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[1], n, nn, O[1], n, nn, n, n, T(1), 0);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[3], n, nn, Y, 2 * n, 2 * nn, one, O[1], n, nn, batch); if (rc) return rc;
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, S[3], n, nn, Y + n, 2 * n, 2 * nn, zero, O[3], n, nn, batch); if (rc) return rc;
+    }
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+// A = P Q for a layer with homogeneous mu (rcwa.py:1236), from the block structure
+//   A = [[mu E - Ky^2 - Kx Gx,  KxKy - Kx Gy], [KxKy - Ky Gx,  mu E - Kx^2 - Ky Gy]],  Gx = E^-1 (Kx E), Gy = E^-1 (Ky E)
+// i.e. two N^3 products instead of one (2N)^3 product.
+template <class T>
+__global__ __launch_bounds__(256) void scale_rows_kernel(const cx<T>* __restrict__ in, const cx<T>* __restrict__ s, int N, cx<T>* __restrict__ out) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const long o = ((long)b * N + i) * N + j;
+    out[o] = s[(long)b * N + i] * in[o];
+}
+template <class T>
+__global__ __launch_bounds__(256) void assemble_a_kernel(const cx<T>* __restrict__ E, const cx<T>* __restrict__ Gx, const cx<T>* __restrict__ Gy,
+                                                         const cx<T>* __restrict__ mu, const cx<T>* __restrict__ kx, const cx<T>* __restrict__ ky, int N,
+                                                         cx<T>* __restrict__ A) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const long o = ((long)b * N + i) * N + j;
+    const cx<T> kxi = kx[(long)b * N + i], kyi = ky[(long)b * N + i];
+    const cx<T> e = mu[b] * E[o], gx = Gx[o], gy = Gy[o];
+    const int n = 2 * N;
+    cx<T>* Ab = A + (long)b * n * n;
+    cx<T> a11 = e - kxi * gx, a12 = -(kxi * gy), a21 = -(kyi * gx), a22 = e - kyi * gy;
+    if (i == j) { a11 -= kyi * kyi; a22 -= kxi * kxi; a12 += kxi * kyi; a21 += kxi * kyi; }
+    Ab[(long)i * n + j] = a11;
+    Ab[(long)i * n + j + N] = a12;
+    Ab[(long)(i + N) * n + j] = a21;
+    Ab[(long)(i + N) * n + j + N] = a22;
+}
+template <class T>
+int build_a_t(hipStream_t s, const cx<T>* E, const cx<T>* Ei, const cx<T>* mu, const cx<T>* kx, const cx<T>* ky, int N, int batch, cx<T>* A, cx<T>* ws) {
+    const long NN = (long)N * N, bNN = (long)batch * NN;
+    const cx<T> one(T(1), T(0)), zero(T(0), T(0));
+    const dim3 g(cdiv_i(N, 256), N, batch), blk(256);
+    cx<T>*Sx = ws, *Gx = ws + bNN, *Gy = ws + 2 * bNN;
+    TRX_LAUNCH((scale_rows_kernel<T>), g, blk, 0, s, E, kx, N, Sx);
+    int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, N, N, N, one, Ei, N, NN, Sx, N, NN, zero, Gx, N, NN, batch); if (rc) return rc;
+    TRX_LAUNCH((scale_rows_kernel<T>), g, blk, 0, s, E, ky, N, Sx);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, N, N, N, one, Ei, N, NN, Sx, N, NN, zero, Gy, N, NN, batch); if (rc) return rc;
+    TRX_LAUNCH((assemble_a_kernel<T>), g, blk, 0, s, E, (const cx<T>*)Gx, (const cx<T>*)Gy, mu, kx, ky, N, A);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 }  // namespace
 }  // namespace trx
 
@@ -247,5 +399,31 @@ extern "C" int trx_redheffer(int dtype, const void* const* Sm, const void* const
     hipStream_t s = (hipStream_t)stream;
     if (dtype == TRX_C64) return redheffer_t<float>(s, (const cx<float>* const*)Sm, (const cx<float>* const*)Sn, (cx<float>* const*)Sout, (cx<float>*)XY, n, batch, piv, info, (cx<float>*)ws);
     if (dtype == TRX_C128) return redheffer_t<double>(s, (const cx<double>* const*)Sm, (const cx<double>* const*)Sn, (cx<double>* const*)Sout, (cx<double>*)XY, n, batch, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}
+
+extern "C" int trx_redheffer_halfspace(int dtype, int side, const void* bd, const void* const* S, void* const* Sout, void* XY, int N, int batch,
+                                       int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
+    if (!bd || !S || !Sout || !XY || !piv || !info || !ws || N <= 0 || batch <= 0 || (side != 0 && side != 1)) return TRX_ERR_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!S[k] || !Sout[k]) return TRX_ERR_ARG;
+    if (ws_bytes < trx_redheffer_ws_bytes(dtype, 2 * N, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRX_C64) return redheffer_halfspace_t<float>(s, side, (const cx<float>*)bd, (const cx<float>* const*)S, (cx<float>* const*)Sout, (cx<float>*)XY, N, batch, piv, info, (cx<float>*)ws);
+    if (dtype == TRX_C128) return redheffer_halfspace_t<double>(s, side, (const cx<double>*)bd, (const cx<double>* const*)S, (cx<double>* const*)Sout, (cx<double>*)XY, N, batch, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}
+
+extern "C" size_t trx_build_a_ws_bytes(int dtype, int N, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * 3 * (size_t)batch * N * N;
+}
+
+extern "C" int trx_build_a(int dtype, const void* E, const void* Einv, const void* mu, const void* kx, const void* ky, int N, int batch, void* A,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!E || !Einv || !mu || !kx || !ky || !A || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
+    if (ws_bytes < trx_build_a_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRX_C64) return build_a_t<float>(s, (const cx<float>*)E, (const cx<float>*)Einv, (const cx<float>*)mu, (const cx<float>*)kx, (const cx<float>*)ky, N, batch, (cx<float>*)A, (cx<float>*)ws);
+    if (dtype == TRX_C128) return build_a_t<double>(s, (const cx<double>*)E, (const cx<double>*)Einv, (const cx<double>*)mu, (const cx<double>*)kx, (const cx<double>*)ky, N, batch, (cx<double>*)A, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
 }

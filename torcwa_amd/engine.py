@@ -177,6 +177,39 @@ class Engine:
         return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
 
 
+    def redheffer_halfspace(self, side, bd, S):
+        """Star product with a block-diagonal half-space S-matrix (side 0: Sin * S, side 1: S * Sout).
+        bd: [4,4,B,N] diagonals (see include/trx.h)."""
+        S = [self._c(t) for t in S]
+        B, n, _ = S[0].shape
+        N = n // 2
+        dt = S[0].dtype
+        bd = self._c(bd.to(dt))
+        out = [torch.empty((B, n, n), dtype=dt, device=self.device) for _ in range(4)]
+        XY = torch.empty((2, B, n, 2 * n), dtype=dt, device=self.device)
+        piv, info = self._ints(B * n), self._ints(B)
+        nws = self.lib.redheffer_ws_bytes(_CODE[dt], n, B)
+        ws = self._ws(nws)
+        arr = ctypes.c_void_p * 4
+        ps, po = arr(*[t.data_ptr() for t in S]), arr(*[t.data_ptr() for t in out])
+        self.lib.check(self.lib.redheffer_halfspace(_CODE[dt], int(side), bd.data_ptr(), ctypes.addressof(ps), ctypes.addressof(po), XY.data_ptr(),
+                                                    N, B, piv.data_ptr(), info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self._info(info, "redheffer_halfspace")
+        X, Y = XY[0], XY[1]
+        return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
+
+    def build_a(self, E, Einv, mu, kx, ky):
+        """A = P Q for homogeneous mu [B] via the block structure (two N^3 GEMMs)."""
+        B, N, _ = E.shape
+        dt = E.dtype
+        A = torch.empty((B, 2 * N, 2 * N), dtype=dt, device=self.device)
+        nws = self.lib.build_a_ws_bytes(_CODE[dt], N, B)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.build_a(_CODE[dt], self._c(E).data_ptr(), self._c(Einv).data_ptr(), self._c(mu.to(dt)).data_ptr(), self._c(kx).data_ptr(),
+                                        self._c(ky).data_ptr(), N, B, A.data_ptr(), ws.data_ptr(), nws, self.stream))
+        return A
+
+
 _default = None
 
 

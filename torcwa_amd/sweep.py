@@ -58,26 +58,72 @@ def rectangle_density(nx, ny, Lx, Ly, Wx, Wy, Cx, Cy, theta=0.0, edge_sharpness=
     return g.rectangle(Wx=Wx, Wy=Wy, Cx=Cx, Cy=Cy, theta=theta)
 
 
+def _solve_chunk(freq, eps_grids, thickness, order, L, eps_in, eps_out, inc_ang, azi_ang, dtype, precision, engine, orders,
+                 polarization, direction, port, check_info):
+    sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
+    sim.engine.check_info = check_info
+    if eps_in is not None:
+        sim.add_input_layer(eps=eps_in)
+    if eps_out is not None:
+        sim.add_output_layer(eps=eps_out)
+    sim.set_incident_angle(inc_ang, azi_ang)
+    sim.add_layer(thickness, eps_grids)
+    sim.solve_global_smatrix()
+    return sim.S_parameters([list(o) for o in orders], direction=direction, port=port, polarization=polarization)
+
+
 def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0,
-                             dtype=torch.complex64, precision="high", engine=None, chunk=None, orders=((0, 0),),
+                             dtype=torch.complex64, precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),),
                              polarization="xx", direction="forward", port="transmission", check_info=True):
     """B sweep points of a 1-patterned-layer stack (config 2/4 of BASELINE.json).  freq [B], eps_grids [B,nx,ny].
-    Returns the requested S-parameter [B, len(orders)]."""
+    Returns the requested S-parameter [B, len(orders)].
+
+    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).
+    streams : number of HIP streams; chunks are dealt to `streams` host threads, each driving its own stream, so the
+              latency-bound stages of one chunk (QR window chase, panel factorisations, convergence read-backs) overlap
+              with the throughput-bound kernels of another.  (ctypes releases the GIL during libtrx calls.)
+    """
+    import threading
     B = freq.shape[0]
     chunk = B if chunk is None else int(chunk)
-    outs = []
-    for lo in range(0, B, chunk):
-        hi = min(B, lo + chunk)
-        sim = BatchedRCWA(freq[lo:hi], order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
-        sim.engine.check_info = check_info
-        if eps_in is not None:
-            sim.add_input_layer(eps=eps_in)
-        if eps_out is not None:
-            sim.add_output_layer(eps=eps_out)
-        sim.set_incident_angle(inc_ang, azi_ang)
-        th = thickness[lo:hi] if torch.is_tensor(thickness) and thickness.dim() > 0 else thickness
-        sim.add_layer(th, eps_grids[lo:hi])
-        sim.solve_global_smatrix()
-        outs.append(sim.S_parameters([list(o) for o in orders], direction=direction, port=port, polarization=polarization))
-        del sim
+    if streams > 1 and chunk >= B:
+        chunk = -(-B // streams)
+    spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
+    outs = [None] * len(spans)
+
+    def th_of(lo, hi):
+        return thickness[lo:hi] if torch.is_tensor(thickness) and thickness.dim() > 0 else thickness
+
+    def run(i):
+        lo, hi = spans[i]
+        outs[i] = _solve_chunk(freq[lo:hi], eps_grids[lo:hi], th_of(lo, hi), order, L, eps_in, eps_out, inc_ang, azi_ang, dtype,
+                               precision, engine, orders, polarization, direction, port, check_info)
+
+    dev = eps_grids.device
+    if streams <= 1 or len(spans) == 1 or dev.type != "cuda":
+        for i in range(len(spans)):
+            run(i)
+    else:
+        cur = torch.cuda.current_stream(dev)
+        pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        errors = []
+
+        def worker(w):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(pool[w]):
+                    pool[w].wait_stream(cur)
+                    for i in range(w, len(spans), streams):
+                        run(i)
+            except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        for st in pool:
+            cur.wait_stream(st)
     return torch.cat(outs, dim=0)
