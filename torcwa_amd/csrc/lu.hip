@@ -186,22 +186,52 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 
 }  // namespace
 
+// Two-level blocking: panels of NB columns are factored one at a time, but the update of everything to the right of
+// the current OUTER block (NBO = 4 panels) is delayed until the whole outer block is done, so the dominant trailing
+// update is a rank-128 GEMM (compute-bound on the matrix cores) instead of four rank-32 updates (HBM-bound: each
+// re-reads and re-writes the trailing matrix).
+constexpr int NBO = 4 * NB;
+
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
     if (n <= 0 || batch <= 0) return TRX_OK;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
     const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int jb = (n - k0 < NB) ? (n - k0) : NB;
-        TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, k0, jb, piv, info);
-        if (n - jb > 0)
-            TRX_LAUNCH((lu_swap_kernel<T>), dim3(cdiv_i(n - jb, 256), batch), dim3(256), 0, s, A, lda, sA, n, k0, jb, (const int*)piv, n);
-        const int rest = n - k0 - jb;
-        if (rest > 0) {
-            TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(rest, 256), batch), dim3(256), 0, s,
-                       (const cx<T>*)(A + (long)k0 * lda + k0), lda, sA, jb, A + (long)k0 * lda + k0 + jb, lda, sA, rest);
-            int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rest, rest, jb, mone, A + (long)(k0 + jb) * lda + k0, lda, sA,
-                             A + (long)k0 * lda + k0 + jb, lda, sA, one, A + (long)(k0 + jb) * lda + k0 + jb, lda, sA, batch);
+    auto at = [&](int r, int c) { return A + (long)r * lda + c; };
+    int rc;
+    for (int K0 = 0; K0 < n; K0 += NBO) {
+        const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
+        const int Kend = K0 + kb;
+        for (int c0 = K0; c0 < Kend; c0 += NB) {
+            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+            TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
+            if (n - jb > 0)
+                TRX_LAUNCH((lu_swap_kernel<T>), dim3(cdiv_i(n - jb, 256), batch), dim3(256), 0, s, A, lda, sA, n, c0, jb, (const int*)piv, n);
+            const int wcols = Kend - (c0 + jb);       // columns of the outer block still to be factored
+            if (wcols > 0) {
+                TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(wcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
+                           at(c0, c0 + jb), lda, sA, wcols);
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - c0 - jb, wcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, c0 + jb), lda, sA, one,
+                             at(c0 + jb, c0 + jb), lda, sA, batch);
+                if (rc) return rc;
+            }
+        }
+        const int tcols = n - Kend;
+        if (tcols > 0) {
+            // U rows of the outer block for the trailing columns: four (trsm + in-block update) steps ...
+            for (int c0 = K0; c0 < Kend; c0 += NB) {
+                const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+                TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(tcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
+                           at(c0, Kend), lda, sA, tcols);
+                const int rin = Kend - (c0 + jb);
+                if (rin > 0) {
+                    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, tcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, Kend), lda, sA, one,
+                                 at(c0 + jb, Kend), lda, sA, batch);
+                    if (rc) return rc;
+                }
+            }
+            // ... then ONE rank-kb update of the trailing matrix
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, tcols, tcols, kb, mone, at(Kend, K0), lda, sA, at(K0, Kend), lda, sA, one, at(Kend, Kend), lda, sA, batch);
             if (rc) return rc;
         }
     }
@@ -215,24 +245,43 @@ int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int*
     if (n <= 0 || nrhs <= 0 || batch <= 0) return TRX_OK;
     const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
     const dim3 cg(cdiv_i(nrhs, 256), batch);
+    auto lu = [&](int r, int c) { return LU + (long)r * lda + c; };
+    auto bb = [&](int r) { return B + (long)r * ldb; };
+    int rc;
     TRX_LAUNCH((rhs_permute_kernel<T>), cg, dim3(256), 0, s, B, ldb, sB, nrhs, piv, n);
-    for (int k0 = 0; k0 < n; k0 += NB) {            // forward: L Y = P B
-        const int jb = (n - k0 < NB) ? (n - k0) : NB;
-        TRX_LAUNCH((trsm_kernel<T, false>), cg, dim3(256), 0, s, LU + (long)k0 * lda + k0, lda, sA, jb, B + (long)k0 * ldb, ldb, sB, nrhs);
-        const int rest = n - k0 - jb;
-        if (rest > 0) {
-            int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rest, nrhs, jb, mone, LU + (long)(k0 + jb) * lda + k0, lda, sA,
-                             B + (long)k0 * ldb, ldb, sB, one, B + (long)(k0 + jb) * ldb, ldb, sB, batch);
+    for (int K0 = 0; K0 < n; K0 += NBO) {            // forward: L Y = P B
+        const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
+        const int Kend = K0 + kb;
+        for (int c0 = K0; c0 < Kend; c0 += NB) {
+            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+            TRX_LAUNCH((trsm_kernel<T, false>), cg, dim3(256), 0, s, lu(c0, c0), lda, sA, jb, bb(c0), ldb, sB, nrhs);
+            const int rin = Kend - (c0 + jb);
+            if (rin > 0) {
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, nrhs, jb, mone, lu(c0 + jb, c0), lda, sA, bb(c0), ldb, sB, one, bb(c0 + jb), ldb, sB, batch);
+                if (rc) return rc;
+            }
+        }
+        if (n - Kend > 0) {
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - Kend, nrhs, kb, mone, lu(Kend, K0), lda, sA, bb(K0), ldb, sB, one, bb(Kend), ldb, sB, batch);
             if (rc) return rc;
         }
     }
-    const int last = ((n - 1) / NB) * NB;
-    for (int k0 = last; k0 >= 0; k0 -= NB) {        // backward: U X = Y
-        const int jb = (n - k0 < NB) ? (n - k0) : NB;
-        TRX_LAUNCH((trsm_kernel<T, true>), cg, dim3(256), 0, s, LU + (long)k0 * lda + k0, lda, sA, jb, B + (long)k0 * ldb, ldb, sB, nrhs);
-        if (k0 > 0) {
-            int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, k0, nrhs, jb, mone, LU + k0, lda, sA, B + (long)k0 * ldb, ldb, sB,
-                             one, B, ldb, sB, batch);
+    const int lastK = ((n - 1) / NBO) * NBO;
+    for (int K0 = lastK; K0 >= 0; K0 -= NBO) {       // backward: U X = Y
+        const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
+        const int Kend = K0 + kb;
+        const int lastc = K0 + ((kb - 1) / NB) * NB;
+        for (int c0 = lastc; c0 >= K0; c0 -= NB) {
+            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+            TRX_LAUNCH((trsm_kernel<T, true>), cg, dim3(256), 0, s, lu(c0, c0), lda, sA, jb, bb(c0), ldb, sB, nrhs);
+            const int rin = c0 - K0;
+            if (rin > 0) {
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, nrhs, jb, mone, lu(K0, c0), lda, sA, bb(c0), ldb, sB, one, bb(K0), ldb, sB, batch);
+                if (rc) return rc;
+            }
+        }
+        if (K0 > 0) {
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, K0, nrhs, kb, mone, lu(0, K0), lda, sA, bb(K0), ldb, sB, one, bb(0), ldb, sB, batch);
             if (rc) return rc;
         }
     }
