@@ -42,7 +42,9 @@ def run_step(freq, grids, order, engine, precision, chunk, streams):
 
 
 def cpu_baseline(order, lam_nm, eps_si, threads):
-    """The reference's CPU path (oracle port, same op sequence), timed on the host cores on a bounded sample."""
+    """The reference's CPU path (oracle port, same op sequence), timed on the host cores on a bounded sample:
+    one layer-solve in complex64 (the timed baseline, as the reference runs it) and the same point in complex128
+    (the parity oracle)."""
     from oracle import rcwa_oracle as orc
     torch.set_num_threads(threads)
     dens = orc.rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., dtype=torch.float32)
@@ -51,7 +53,11 @@ def cpu_baseline(order, lam_nm, eps_si, threads):
     s, lays, S, C = orc.solve_stack(1.0 / float(lam_nm), order, [300., 300.], [(300., eps, 1.0)], dtype=torch.complex64, eps_in=1.46 ** 2)
     v = orc.s_parameters(s, S, [0, 0])
     dt = time.perf_counter() - t0
-    return dt, complex(v[0])
+    t1 = time.perf_counter()
+    s, lays, S, C = orc.solve_stack(1.0 / float(lam_nm), order, [300., 300.], [(300., eps.to(torch.complex128), 1.0)], dtype=torch.complex128, eps_in=1.46 ** 2)
+    v128 = orc.s_parameters(s, S, [0, 0])
+    dt128 = time.perf_counter() - t1
+    return dt, complex(v[0]), dt128, complex(v128[0])
 
 
 # MI355X dense matrix-core peaks for the arithmetic type of the path.  f32: 157.3 TF (MI355X_MICROARCH.md, "Peak FP32
@@ -170,7 +176,12 @@ def main():
             threads = args.cpu_threads if args.cpu_threads > 0 else max(1, (os.cpu_count() or 2) // 2)
             from torcwa_amd.sweep import asih_eps_table
             lam, eps_si = asih_eps_table()
-            dt, v = cpu_baseline(order, lam[0], eps_si[0], threads)
+            dt, v, dt128, v128 = cpu_baseline(order, lam[0], eps_si[0], threads)
+            got = complex(full[0, 0])
+            res["parity_sample"] = {"point": "lambda=%.1f nm, txx(0,0)" % lam[0], "gpu": [got.real, got.imag],
+                                    "oracle_c128": [v128.real, v128.imag], "rel_err_vs_c128_oracle": abs(got - v128) / abs(v128),
+                                    "oracle_c64": [v.real, v.imag], "rel_err_of_c64_oracle_vs_c128_oracle": abs(v - v128) / abs(v128),
+                                    "oracle_c128_seconds": dt128}
             res["cpu_baseline"] = {"value": 1.0 / dt, "unit": "layer-solves/s", "cores": threads, "kind": "port",
                                    "sample": "1 layer-solve (lambda=%.1f nm) of the same workload, complex64, oracle/rcwa_oracle.py on torch-CPU; "
                                              "txx00=%.6f%+.6fj" % (lam[0], v.real, v.imag)}

@@ -203,5 +203,76 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--fields" not in sys.argv:
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# field-map golden vectors: sources + field_xz / field_yz / field_xy
+# ---------------------------------------------------------------------------------------------------------
+def field_case(name, *, freq, order, L, layers, eps_in=None, eps_out=None, inc=0.0, azi=0.0, angle_layer="input", dtype="c128"):
+    cdt = torch.complex128
+    sim = torcwa.rcwa(freq=freq, order=order, L=L, dtype=cdt, device=torch.device("cpu"), stable_eig_grad=False)
+    if eps_in is not None:
+        sim.add_input_layer(eps=eps_in)
+    if eps_out is not None:
+        sim.add_output_layer(eps=eps_out)
+    sim.set_incident_angle(inc_ang=inc, azi_ang=azi, angle_layer=angle_layer)
+    for (d, eps, mu) in layers:
+        sim.add_layer(thickness=d, eps=eps, mu=mu)
+    sim.solve_global_smatrix()
+    tot = sum(d for d, _, _ in layers)
+    x = torch.tensor([3.0, 77.5, 150.0, 211.0, 299.0], dtype=torch.float64)
+    y = torch.tensor([10.0, 120.0, 205.5], dtype=torch.float64)
+    zs = [-120.0, -1.0, 0.0, 0.5]
+    acc = 0.0
+    for d, _, _ in layers:
+        zs += [acc + 0.3 * d, acc + d]
+        acc += d
+    zs += [tot + 0.5, tot + 90.0]
+    z = torch.tensor(zs, dtype=torch.float64)
+    out = {"x": x.numpy(), "y": y.numpy(), "z": z.numpy()}
+    srcs = [("planewave_xy_f", dict(kind="pw", amplitude=[1.0, 0.5j], direction="forward", notation="xy")),
+            ("planewave_ps_b", dict(kind="pw", amplitude=[0.3, 1.0], direction="backward", notation="ps")),
+            ("fourier_xy_f", dict(kind="fo", amplitude=[[1.0, 0.2], [0.1j, 0.4]], orders=[[0, 0], [1, -1]], direction="f", notation="xy"))]
+    for sname, kw in srcs:
+        kw = dict(kw)
+        kind = kw.pop("kind")
+        if kind == "pw":
+            sim.source_planewave(**kw)
+        else:
+            sim.source_fourier(**kw)
+        out[f"{sname}_Ei"] = sim.E_i.numpy()
+        E, H = sim.field_xz(x, z, 133.0)
+        out[f"{sname}_xz"] = np.stack([t.numpy() for t in E + H])
+        E, H = sim.field_yz(y, z, 41.0)
+        out[f"{sname}_yz"] = np.stack([t.numpy() for t in E + H])
+        for ln, zp in [(-1, -35.0), (0, 0.4 * layers[0][0] if layers else 0.0), (len(layers) - 1, 10.0), (len(layers), 25.0)]:
+            if ln < -1 or (not layers and ln in (0, len(layers) - 1) and ln != len(layers)):
+                continue
+            if ln >= 0 and ln < len(layers) or ln in (-1, len(layers)):
+                E, H = sim.field_xy(int(ln), x, y, zp)
+                out[f"{sname}_xy_L{ln}"] = np.stack([t.numpy() for t in E + H])
+                out[f"{sname}_xy_L{ln}_zprop"] = np.float64(zp)
+    path = os.path.join(HERE, f"fields_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"fields_{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main_fields():
+    lam_tab = np.load(os.path.join(HERE, "asih_table.npz"))
+    nk532 = complex(lam_tab["nk"][-2])
+    eps_si = nk532 ** 2
+    # small grids (the field fixtures reuse the inputs stored in the S-matrix fixtures of the same name)
+    z = np.load(os.path.join(HERE, "example1_o3_c128.npz"))
+    eps1 = torch.from_numpy(z["L0_eps_grid"])
+    field_case("example1_o3", freq=1 / 532., order=[3, 3], L=[300., 300.], layers=[(300., eps1, 1.0)], eps_in=1.46 ** 2)
+    z = np.load(os.path.join(HERE, "asym_o32_c128.npz"))
+    lays = [(150., torch.from_numpy(z["L0_eps_grid"]), torch.from_numpy(z["L0_mu_grid"])), (80., 2.25, 1.0),
+            (120., torch.from_numpy(z["L2_eps_grid"]), 1.0)]
+    field_case("asym_o32", freq=1 / 600., order=[3, 2], L=[320., 410.], layers=lays, eps_in=2.1, eps_out=1.7,
+               inc=20 * np.pi / 180, azi=35 * np.pi / 180, angle_layer="output")
+
+
+if __name__ == "__main__" and "--fields" in sys.argv:
+    main_fields()

@@ -7,11 +7,12 @@ libtrx kernels behind include/trx.h).  Attributes are exposed un-batched and in 
 import torch
 
 from .batched import BatchedRCWA, PI_REF
+from .fields import FieldMixin
 
 pi = PI_REF
 
 
-class rcwa:
+class rcwa(FieldMixin):
     def __init__(self, freq, order, L, *, dtype=torch.complex64, device=None, stable_eig_grad=True,
                  avoid_Pinv_instability=False, max_Pinv_instability=0.005, precision="high", engine=None):
         self._b = BatchedRCWA(freq, order, L, batch=1, dtype=dtype, device=device, stable_eig_grad=stable_eig_grad,
@@ -68,6 +69,26 @@ class rcwa:
 
     def _matching_indices(self, orders):
         return self._b._matching_indices(orders)
+
+    def return_layer(self, layer_num, nx=100, ny=100):                                  # rcwa.py:264-298
+        """eps(x,y), mu(x,y) of a layer recovered from the truncated Fourier series held in its convolution matrix."""
+        ox, oy = self.order
+        wy = 2 * oy + 1
+        outs = []
+        for conv in (self._b.eps_conv[layer_num][0], self._b.mu_conv[layer_num][0]):
+            f = torch.zeros([nx, ny], dtype=conv.dtype, device=self._device)
+            for i in range(-2 * ox, 2 * ox + 1):
+                for j in range(-2 * oy, 2 * oy + 1):
+                    if i >= 0 and j >= 0:
+                        f[i, j] = conv[i * wy + j, 0]
+                    elif i >= 0 and j < 0:
+                        f[i, j] = conv[i * wy, -j]
+                    elif i < 0 and j >= 0:
+                        f[i, j] = conv[j, -i * wy]
+                    else:
+                        f[i, j] = conv[0, -i * wy - j]
+            outs.append((torch.fft.ifftn(f) * nx * ny).to(self._dtype))
+        return outs[0], outs[1]
 
     # ---- un-batched attribute views ----------------------------------------------------------------------------
     def _u(self, t):
