@@ -203,7 +203,7 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__" and "--fields" not in sys.argv:
+if __name__ == "__main__" and "--fields" not in sys.argv and "--grad" not in sys.argv:
     main()
 
 
@@ -276,3 +276,45 @@ def main_fields():
 
 if __name__ == "__main__" and "--fields" in sys.argv:
     main_fields()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# gradient golden vectors (config 5 of BASELINE.json at a small order): FoM, dFoM/d(density), dFoM/d(thickness)
+# ---------------------------------------------------------------------------------------------------------
+def main_grad():
+    lam_tab = np.load(os.path.join(HERE, "asih_table.npz"))
+    eps_si = complex(lam_tab["nk"][-2]) ** 2
+    gen = torch.Generator().manual_seed(333)
+    rho0 = torch.rand(40, 36, generator=gen, dtype=torch.float64)
+    rho0 = (rho0 + torch.flip(rho0, dims=[1])) / 2          # symmetrised like Example6
+    out = {"rho": rho0.numpy(), "eps_si": np.complex128(eps_si)}
+    for stable, bp in ((True, 1e-10), (True, None), (False, 1e-10)):
+        torcwa.Eig.broadening_parameter = bp
+        rho = rho0.clone().requires_grad_(True)
+        thick = torch.tensor(300., dtype=torch.float64, requires_grad=True)
+        sim = torcwa.rcwa(freq=1 / 532., order=[3, 2], L=[700., 300.], dtype=torch.complex128, device=torch.device("cpu"),
+                          stable_eig_grad=stable)
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        eps = rho * eps_si + (1. - rho)
+        sim.add_layer(thickness=thick, eps=eps)
+        sim.add_layer(thickness=80., eps=2.25)
+        sim.solve_global_smatrix()
+        t1xx = sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+        t1yx = sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization="yx", ref_order=[0, 0])
+        t1xy = sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization="xy", ref_order=[0, 0])
+        t1yy = sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization="yy", ref_order=[0, 0])
+        fom = torch.abs(t1xx) ** 2 + torch.abs(t1yx) ** 2 + torch.abs(t1xy) ** 2 + torch.abs(t1yy) ** 2
+        fom.sum().backward()
+        tag = f"stable{int(stable)}_bp{'none' if bp is None else 'e-10'}"
+        out[f"{tag}_fom"] = fom.detach().numpy()
+        out[f"{tag}_t1xx"] = t1xx.detach().numpy()
+        out[f"{tag}_grad_rho"] = rho.grad.numpy()
+        out[f"{tag}_grad_thick"] = thick.grad.numpy()
+        print(tag, "FoM", float(fom), "sum dFoM/drho", float(rho.grad.sum()), "dFoM/dd", float(thick.grad))
+    torcwa.Eig.broadening_parameter = 1e-10
+    np.savez_compressed(os.path.join(HERE, "grad_o32.npz"), **out)
+
+
+if __name__ == "__main__" and "--grad" in sys.argv:
+    main_grad()

@@ -1,0 +1,45 @@
+"""Gradients through the HIP path (config 5 of BASELINE.json at a small order) against golden vectors produced by the
+reference's autograd (tests/golden/grad_o32.npz; make_golden.py --grad): FoM = sum_pol |t_(1,0),pol|^2 of a 2-layer stack,
+d FoM / d density (40x36 grid) and d FoM / d thickness, for stable_eig_grad True (broadening 1e-10 and None) and False.
+Tolerance 1e-6 relative (broadening makes the gradient approximate by design)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.backends import BACKENDS
+from tests.helpers import GOLDEN
+from tests.test_pipeline import make_engine
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("stable,bp,tag", [(True, 1e-10, "stable1_bpe-10"), (True, None, "stable1_bpnone"), (False, 1e-10, "stable0_bpe-10")])
+def test_gradient_matches_reference(backend, stable, bp, tag):
+    import torcwa_amd
+    eng = make_engine(backend)
+    g = np.load(os.path.join(GOLDEN, "grad_o32.npz"))
+    eps_si = complex(g["eps_si"])
+    old = torcwa_amd.Eig.broadening_parameter
+    torcwa_amd.Eig.broadening_parameter = bp
+    try:
+        rho = torch.from_numpy(g["rho"]).to(eng.device).requires_grad_(True)
+        thick = torch.tensor(300., dtype=torch.float64, device=eng.device, requires_grad=True)
+        sim = torcwa_amd.rcwa(freq=1 / 532., order=[3, 2], L=[700., 300.], dtype=torch.complex128, engine=eng, stable_eig_grad=stable)
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        sim.add_layer(thickness=thick, eps=rho * eps_si + (1. - rho))
+        sim.add_layer(thickness=80., eps=2.25)
+        sim.solve_global_smatrix()
+        t = [sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization=p, ref_order=[0, 0]) for p in ("xx", "yx", "xy", "yy")]
+        fom = sum(torch.abs(v) ** 2 for v in t)
+        fom.sum().backward()
+    finally:
+        torcwa_amd.Eig.broadening_parameter = old
+    fom_v, fom_ref = float(fom.detach().reshape(-1)[0]), float(np.asarray(g[f"{tag}_fom"]).reshape(-1)[0])
+    assert abs(fom_v - fom_ref) / fom_ref < 1e-9
+    gr = rho.grad.cpu().numpy()
+    ref = g[f"{tag}_grad_rho"]
+    assert np.abs(gr - ref).max() / np.abs(ref).max() < 1e-6
+    gt_ref = float(np.asarray(g[f"{tag}_grad_thick"]).reshape(-1)[0])
+    assert abs(float(thick.grad.reshape(-1)[0]) - gt_ref) / abs(gt_ref) < 1e-6

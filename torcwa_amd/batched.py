@@ -12,6 +12,8 @@ import warnings
 import torch
 
 from .engine import Engine, default_engine
+from . import autograd_ops as ag
+from .torch_eig import Eig
 
 # torcwa/rcwa.py:5 -- the reference's pi (typo in the 9th decimal) is part of its observable behaviour
 PI_REF = 3.141592652589793
@@ -174,6 +176,10 @@ class BatchedRCWA:
         eng, N, B, cdt = self.engine, self.order_N, self.B, self._cdtype
         eps_h, mu_h = self._is_homogeneous(eps), self._is_homogeneous(mu)
         eye = torch.eye(N, dtype=cdt, device=self._device)
+        # differentiable path (Examples 4-6): every O(n^3) primitive is an autograd.Function over the same HIP kernels
+        diff = torch.is_grad_enabled() and any(torch.is_tensor(v) and v.requires_grad for v in
+                                               (thickness, eps, mu, self.freq, self.Kx_norm_dn, self.Ky_norm_dn))
+        self._diff = getattr(self, "_diff", False) or diff
 
         def conv(v, homog):
             if homog:
@@ -182,6 +188,8 @@ class BatchedRCWA:
             g = torch.as_tensor(v, device=self._device)
             if g.dim() == 2:
                 g = g[None].expand(B, -1, -1)
+            if diff:
+                return ag.ConvMatFn.apply(g.contiguous(), self.order[0], self.order[1], cdt, eng), None, None
             C = eng.convmat(g.contiguous(), self.order[0], self.order[1], cdt)          # rcwa.py:1183-1204
             return C, None, None
 
@@ -193,29 +201,95 @@ class BatchedRCWA:
         d = self._bvec(thickness, self._rdtype)
         self.thickness.append(d)
         kxd, kyd = self.Kx_norm_dn, self.Ky_norm_dn
-        if eps_h and mu_h:                                                              # rcwa.py:1206-1222
+        inv = (lambda A: ag.InverseFn.apply(A, eng)) if diff else eng.inverse
+        if Einv is None:
+            Einv = inv(E)
+        if Minv is None:
+            Minv = inv(M)
+        if diff:
+            P, Q = self._pq_torch(E, Einv, M, Minv, kxd, kyd)
+        else:
             P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
+        if eps_h and mu_h:                                                              # rcwa.py:1206-1222
             W = torch.eye(2 * N, dtype=cdt, device=self._device).expand(B, -1, -1).contiguous()
             kz = torch.sqrt((eps_s * mu_s)[:, None] - kxd ** 2 - kyd ** 2)
             kz = torch.where(torch.imag(kz) < 0, torch.conj(kz), kz)
             kz = torch.cat((kz, kz), dim=1)
         else:                                                                           # rcwa.py:1224-1242
-            if Einv is None:
-                Einv = eng.inverse(E)
-            if Minv is None:
-                Minv = eng.inverse(M)
-            P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
-            # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
-            A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
-            lam, W = eng.eig(A, destroy=True)                                           # torch_eig.py:14
-            del A
+            if diff:
+                old_bp = Eig.broadening_parameter
+                if not self.stable_eig_grad:      # reference: plain torch.linalg.eig backward (no broadening)
+                    Eig.broadening_parameter = None
+                Eig.engine = eng
+                try:
+                    lam, W = Eig.apply(ag.GemmFn.apply(P, Q, eng))
+                finally:
+                    Eig.broadening_parameter = old_bp
+                self._eig_bp = None if not self.stable_eig_grad else "global"
+            else:
+                # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
+                A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
+                lam, W = eng.eig(A, destroy=True)                                       # torch_eig.py:14
+                del A
             kz = torch.sqrt(lam)
             kz = torch.where(torch.imag(kz) < 0, -kz, kz)                               # rcwa.py:1241
         self.P.append(P)
         self.Q.append(Q)
         self.kz_norm.append(kz)
         self.E_eigvec.append(W)
-        self._solve_layer_smatrix()
+        if diff:
+            self._solve_layer_smatrix_diff()
+        else:
+            self._solve_layer_smatrix()
+
+    @staticmethod
+    def _pq_torch(E, Ei, M, Mi, kx, ky):
+        """P, Q (rcwa.py:1226-1232) with broadcasting instead of dense diagonal products (differentiable)."""
+        kxi, kyi, kxj, kyj = kx[:, :, None], ky[:, :, None], kx[:, None, :], ky[:, None, :]
+        P = torch.cat((torch.cat((kxi * Ei * kyj, M - kxi * Ei * kxj), dim=2),
+                       torch.cat((kyi * Ei * kyj - M, -(kyi * Ei * kxj)), dim=2)), dim=1)
+        Q = torch.cat((torch.cat((-(kxi * Mi * kyj), kxi * Mi * kxj - E), dim=2),
+                       torch.cat((E - kyi * Mi * kyj, kyi * Mi * kxj), dim=2)), dim=1)
+        return P, Q
+
+    def _solve_layer_smatrix_diff(self):
+        """Layer S-matrix (rcwa.py:1244-1281) from differentiable primitives; same lean algebra as trx_layer_smatrix."""
+        eng, N, n = self.engine, self.order_N, self.n
+        P, W, kz, d = self.P[-1], self.E_eigvec[-1], self.kz_norm[-1], self.thickness[-1]
+        X = torch.exp(1j * (self.omega * d)[:, None] * kz)                              # [B, n]
+        V = ag.SolveFn.apply(P, W * kz[:, None, :], eng)                                # P^-1 W Kz
+        p11, p12, p21, p22 = [t.to(self._cdtype)[:, :, None] for t in self._Vfinv.d]
+        F = torch.cat((p11 * V[:, :N] + p12 * V[:, N:], p21 * V[:, :N] + p22 * V[:, N:]), dim=1)    # Vf^-1 V
+        A_, B_ = W + F, (W - F) * X[:, None, :]
+        Tip, Tim = ag.InverseFn.apply(A_ + B_, eng), ag.InverseFn.apply(A_ - B_, eng)
+        cp, cm = Tip + Tim, Tip - Tim
+        I = torch.eye(n, dtype=self._cdtype, device=self._device)
+        S11 = ag.GemmFn.apply(W, X[:, :, None] * cp + cm, eng)
+        S21 = ag.GemmFn.apply(W, cp + X[:, :, None] * cm, eng) - I
+        self.H_eigvec.append(V)
+        self.layer_S11.append(S11)
+        self.layer_S21.append(S21)
+        self.Cplus.append(cp)
+        self.Cminus.append(cm)
+
+    def _RS_prod_diff(self, Sm, Sn, Cm, Cn):
+        """Star product (rcwa.py:1283-1306) from differentiable primitives (one factorisation, push-through identity)."""
+        eng, n = self.engine, self.n
+        I = torch.eye(n, dtype=self._cdtype, device=self._device)
+        mm = lambda a, b: ag.GemmFn.apply(a.contiguous(), b.contiguous(), eng)
+        K = I - mm(Sm[2], Sn[1])
+        X12 = ag.SolveFn.apply(K, torch.cat((Sm[0], mm(Sm[2], Sn[3])), dim=2).contiguous(), eng)
+        X1, X2 = X12[:, :, :n], X12[:, :, n:]
+        Y1, Y2 = mm(Sn[1], X1), Sn[3] + mm(Sn[1], X2)
+        S = [mm(Sn[0], X1), Sm[1] + mm(Sm[3], Y1), Sn[2] + mm(Sn[0], X2), mm(Sm[3], Y2)]
+        C = [[], []]
+        for m in range(len(Cm[0])):
+            C[0].append(Cm[0][m] + mm(Cm[1][m], Y1))
+            C[1].append(mm(Cm[1][m], Y2))
+        for k in range(len(Cn[0])):
+            C[0].append(mm(Cn[0][k], X1))
+            C[1].append(Cn[1][k] + mm(Cn[0][k], X2))
+        return S, C
 
     def _is_homogeneous(self, v):
         if isinstance(v, (float, complex)):
@@ -258,6 +332,8 @@ class BatchedRCWA:
     # ---- a9 / a10 ----------------------------------------------------------------------------------------
     def _RS_prod(self, Sm, Sn, Cm, Cn):                                                 # rcwa.py:1283-1306
         eng = self.engine
+        if getattr(self, "_diff", False):
+            return self._RS_prod_diff(Sm, Sn, Cm, Cn)
         S, X1, X2, Y1, Y2 = eng.redheffer(Sm, Sn)
         C = [[], []]
         for m in range(len(Cm[0])):
@@ -271,6 +347,9 @@ class BatchedRCWA:
     def _RS_halfspace(self, side, Sbd, S, C):
         """Star product with Sin (side 0) / Sout (side 1), whose blocks are 2x2-block-diagonal: O(n^2) products with them."""
         eng = self.engine
+        if getattr(self, "_diff", False):
+            dense = [blk.dense().to(self._cdtype) for blk in Sbd]
+            return self._RS_prod_diff(dense, S, [[], []], C) if side == 0 else self._RS_prod_diff(S, dense, C, [[], []])
         bd = torch.stack([torch.stack(blk.d, dim=0) for blk in Sbd], dim=0).to(self._cdtype).contiguous()   # [4,4,B,N]
         Sn, X1, X2, Y1, Y2 = eng.redheffer_halfspace(side, bd, S)
         Cn = [[], []]
