@@ -2,7 +2,8 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torcwa_amd._lib import lib
 L = lib()
 torch.manual_seed(0)

@@ -1,7 +1,8 @@
 """Ad-hoc GEMM micro-benchmark on the GPU (not a pytest file): TFLOP/s of trx_gemm for the shapes of the hot path."""
 import ctypes, sys, time
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torcwa_amd._lib import lib
 L = lib()
 dt = torch.complex128
