@@ -23,7 +23,7 @@ struct QrState {
     int fail;            // number of unconverged eigenvalues on failure
     int pad;
 };
-enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4 };
+enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
 
 template <class T>
 struct EigBuffers {

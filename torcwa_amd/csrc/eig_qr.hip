@@ -13,8 +13,8 @@
 //                                         trailing k x k block (in-LDS single-shift QR); blocks <= QNMIN are
 //                                         finished here by the same in-LDS QR with U accumulated.
 //   qr_window_kernel   (256 thr / matrix) one window step of the bulge chain.
-//   apply_left_kernel  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n]
-//   apply_right_kernel H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U
+//   apply_window_kernel  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n] ;  H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;
+//                        Z[:, w0:w1] <- Z[:, w0:w1] U        (one launch, disjoint slabs, MFMA)
 #include "eig.hpp"
 #include "mfma.hpp"
 #include "prof.hpp"
@@ -380,6 +380,15 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     // nd > 0: commit the window in Schur/Hessenberg form and publish V for the off-window update
     if (ns == 0) spike = cx<T>(T(0), T(0));
+    // LAPACK's "nibble" rule: after a small deflation (< 14 % of the window) the undeflated window eigenvalues are used
+    // as shifts of a sweep in the SAME outer iteration (first window slot applies V, the following ones chase).
+    const int m2 = (ihi - nd) - ilo + 1;
+    int kch = 0;
+    if (nd * 100 < 14 * nw && m2 > QNMIN && ns >= 2) {
+        kch = (m2 / 2 < QNS) ? m2 / 2 : QNS;
+        if (kch > ns) kch = ns;
+        if (lane < kch) sh[lane] = Hs[(ns - kch + lane) * SLD + ns - kch + lane];     // eigenvalues, before the restore below
+    }
     if (ns > 1 && (spike.x != T(0) || spike.y != T(0))) {
         // reflector that maps the spike s*conj(V[0,0:ns]) onto e1, then return T[0:ns,0:ns] to Hessenberg form
         cx<T>* vw = vwork;
@@ -408,7 +417,16 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         }
         if (lane == 0) {
             H[(long)kw * n + kw - 1] = spike * conj(Us[0]);
-            st.w0 = kw; st.w1 = ihi + 1; st.mode = QR_SMALL_PENDING; st.stall = 0;
+            st.w0 = kw; st.w1 = ihi + 1; st.stall = 0;
+            if (kch >= 2) {
+                st.mode = QR_AED_CHASE;
+                st.ihi = ihi - nd;
+                st.k = kch; st.tau = 0; st.tau_last = (st.ihi - 1 - ilo) + 2 * (kch - 1);
+                st.sweeps += 1;
+                atomicMax(&summary[1], m2);
+            } else {
+                st.mode = QR_SMALL_PENDING;
+            }
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
             atomicOr(&summary[2], 1);
@@ -432,6 +450,7 @@ __global__ __launch_bounds__(256) void qr_window_kernel(cx<T>* __restrict__ Aall
     __syncthreads();
     const QrState st = sst;
     if (st.mode == QR_SMALL_PENDING) { if (t == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }
+    if (st.mode == QR_AED_CHASE) { if (t == 0) st_all[b].mode = QR_CHASE; return; }      // this slot applies the AED unitary
     if (st.mode != QR_CHASE || st.tau > st.tau_last) {
         if (t == 0 && (st.w0 != 0 || st.w1 != 0)) { st_all[b].w0 = 0; st_all[b].w1 = 0; }
         return;
@@ -517,17 +536,15 @@ constexpr int APLANE = (64 * ALD > KC * MLD) ? 64 * ALD : KC * MLD;
 
 // H[w0:w1, cs:cs+64) <- U^H H[w0:w1, cs:cs+64),  cs = w1 + 64*blockIdx.x
 template <class T>
-__global__ __launch_bounds__(256) void apply_left_kernel(cx<T>* __restrict__ Aall, int n, const QrState* __restrict__ st_all,
-                                                         const cx<T>* __restrict__ Uall) {
-    TRX_DYN_SMEM(smem);
+__device__ __forceinline__ void apply_left_body(char* smem, int bx, int b, cx<T>* __restrict__ Aall, int n, const QrState* __restrict__ st_all,
+                                                const cx<T>* __restrict__ Uall) {
     T* Ar = reinterpret_cast<T*>(smem);       // (U^H)[i][k] = conj(U[k][i]) : i-contiguous  [k*MLD + i]
     T* Ai = Ar + APLANE;
     T* Br = Ai + APLANE;                      // X[k][col] : col-contiguous  [k*MLD + col]
     T* Bi = Br + APLANE;
-    const int b = blockIdx.y;
     const int w0 = st_all[b].w0, w1 = st_all[b].w1;
     const int ww = w1 - w0;
-    const int cs = w1 + 64 * blockIdx.x;
+    const int cs = w1 + 64 * bx;
     if (ww <= 0 || cs >= n) return;
     const int nc = (n - cs < 64) ? n - cs : 64;
     cx<T>* H = Aall + (long)b * n * n;
@@ -569,19 +586,17 @@ __global__ __launch_bounds__(256) void apply_left_kernel(cx<T>* __restrict__ Aal
 
 // X[rs:rs+64, w0:w1) <- X[rs:rs+64, w0:w1) U  for X = H (rows < w0; blockIdx.x < nslab) and X = Z (all rows)
 template <class T>
-__global__ __launch_bounds__(256) void apply_right_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n, int nslab,
-                                                          const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall) {
-    TRX_DYN_SMEM(smem);
+__device__ __forceinline__ void apply_right_body(char* smem, int bx, int b, cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n, int nslab,
+                                                 const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall) {
     T* Ar = reinterpret_cast<T*>(smem);       // X[row][k] : k-contiguous  [row*ALD + k]
     T* Ai = Ar + APLANE;
     T* Br = Ai + APLANE;                      // U[k][col] : col-contiguous  [k*MLD + col]
     T* Bi = Br + APLANE;
-    const int b = blockIdx.y;
     const int w0 = st_all[b].w0, w1 = st_all[b].w1;
     const int ww = w1 - w0;
     if (ww <= 0) return;
-    const bool isZ = (int)blockIdx.x >= nslab;
-    const int rs = 64 * (isZ ? (int)blockIdx.x - nslab : (int)blockIdx.x);
+    const bool isZ = bx >= nslab;
+    const int rs = 64 * (isZ ? bx - nslab : bx);
     const int rend = isZ ? n : w0;
     if (rs >= rend) return;
     const int nr = (rend - rs < 64) ? rend - rs : 64;
@@ -627,6 +642,17 @@ __global__ __launch_bounds__(256) void apply_right_kernel(cx<T>* __restrict__ Aa
     }
 }
 
+// One launch per window step updates everything off the window: blockIdx.x in [0, nslab) are the column slabs of the
+// left update, [nslab, 3 nslab) the row slabs of the right update of H and of Z (the three regions are disjoint).
+template <class T>
+__global__ __launch_bounds__(256) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n, int nslab,
+                                                           const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall) {
+    TRX_DYN_SMEM(smem);
+    const int b = blockIdx.y, bx = blockIdx.x;
+    if (bx < nslab) apply_left_body<T>(smem, bx, b, Aall, n, st_all, Uall);
+    else apply_right_body<T>(smem, bx - nslab, b, Aall, Zall, n, nslab, st_all, Uall);
+}
+
 template <class T>
 __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __restrict__ info, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -641,8 +667,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
     const size_t smw = sm2 + sizeof(QrState);
     const size_t sma = sizeof(T) * 4 * APLANE;
-    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_left_kernel<T>, sma) ||
-        set_max_dyn_smem((const void*)apply_right_kernel<T>, sma))
+    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T>, sma))
         return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
     const int max_sweeps = 30 * n + 100;
@@ -655,14 +680,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (hipMemcpyAsync(summary, B.summary, sizeof(int) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
         if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
         if (summary[0] == 0) break;
-        const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 1 : 1;
+        const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 2 : 1;
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, s, 0, 0);
               TRX_LAUNCH((qr_window_kernel<T>), dim3(batch), dim3(256), smw, s, B.A, n, B.st, B.U, (const cx<T>*)B.shifts); }
-            { ProfScope p(PROF_QR_APPLY_LEFT, s, 0, 0);
-              TRX_LAUNCH((apply_left_kernel<T>), dim3(nslab, batch), dim3(256), sma, s, B.A, n, (const QrState*)B.st, (const cx<T>*)B.U); }
             { ProfScope p(PROF_QR_APPLY_RIGHT, s, 0, 0);
-              TRX_LAUNCH((apply_right_kernel<T>), dim3(2 * nslab, batch), dim3(256), sma, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U); }
+              TRX_LAUNCH((apply_window_kernel<T>), dim3(3 * nslab, batch), dim3(256), sma, s, B.A, B.Z, n, nslab, (const QrState*)B.st, (const cx<T>*)B.U); }
         }
     }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch);
