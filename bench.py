@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sweep points per step per GPU")
     ap.add_argument("--order", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=0, help="points solved concurrently (0 = whole batch)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams (host threads) the chunks of a step are dealt to")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -149,6 +149,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     engine.lib.prof_enable(0)
+    n_fail = engine.failures()
+    if n_fail:
+        raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,7 +172,7 @@ def main():
             "config": {"workload": "configs[1]: single patterned layer, order=[%d,%d] (n=%d), 300x300 grid, %d-lambda sweep per GPU, "
                                    "glass input half-space" % (args.order, args.order, n, args.batch),
                        "batch_per_gpu": args.batch, "chunk": chunk, "streams": args.streams, "precision": args.precision},
-            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)],
+            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "numerical_failures": 0,
         }
         res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed)
         if not args.no_cpu_baseline and world == 1:

@@ -32,6 +32,7 @@ class Engine:
         self.lib = lib
         self.device = torch.device(device if device is not None else "cpu")
         self.check_info = True
+        self._fail_acc = None          # device-side count of non-zero info entries seen while check_info is False
 
     # -- helpers ---------------------------------------------------------------------------------------
     @property
@@ -50,7 +51,17 @@ class Engine:
     def _c(t):
         return t if t.is_contiguous() else t.contiguous()
 
+    def failures(self):
+        """Number of batch entries that reported a numerical failure since the last call (one host sync)."""
+        n = 0 if self._fail_acc is None else int(self._fail_acc)
+        self._fail_acc = None
+        return n
+
     def _info(self, info, what):
+        if not self.check_info:        # deferred, sync-free accounting (throughput runs); read with failures()
+            c = (info != 0).sum()
+            self._fail_acc = c if self._fail_acc is None else self._fail_acc + c
+            return
         if self.check_info:
             bad = int((info != 0).sum())
             if bad:
