@@ -58,8 +58,9 @@ def rectangle_density(nx, ny, Lx, Ly, Wx, Wy, Cx, Cy, theta=0.0, edge_sharpness=
     return g.rectangle(Wx=Wx, Wy=Wy, Cx=Cx, Cy=Cy, theta=theta)
 
 
-def _solve_chunk(freq, eps_grids, thickness, order, L, eps_in, eps_out, inc_ang, azi_ang, dtype, precision, engine, orders,
+def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtype, precision, engine, orders,
                  polarization, direction, port, check_info):
+    """layers: list of (thickness, eps[, mu]); thickness scalar or [b]; eps/mu scalar, [b] or [b,nx,ny]."""
     sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
     sim.engine.check_info = check_info
     if eps_in is not None:
@@ -67,22 +68,22 @@ def _solve_chunk(freq, eps_grids, thickness, order, L, eps_in, eps_out, inc_ang,
     if eps_out is not None:
         sim.add_output_layer(eps=eps_out)
     sim.set_incident_angle(inc_ang, azi_ang)
-    sim.add_layer(thickness, eps_grids)
+    for lay in layers:
+        sim.add_layer(*lay)
     sim.solve_global_smatrix()
     return sim.S_parameters([list(o) for o in orders], direction=direction, port=port, polarization=polarization)
 
 
-def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0,
-                             dtype=torch.complex64, precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),),
-                             polarization="xx", direction="forward", port="transmission", check_info=True):
-    """B sweep points of a 1-patterned-layer stack (config 2/4 of BASELINE.json).  freq [B], eps_grids [B,nx,ny].
-    Returns the requested S-parameter [B, len(orders)].
+def _slice(v, lo, hi, B):
+    return v[lo:hi] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v
 
-    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).
-    streams : number of HIP streams; chunks are dealt to `streams` host threads, each driving its own stream, so the
-              latency-bound stages of one chunk (QR window chase, panel factorisations, convergence read-backs) overlap
-              with the throughput-bound kernels of another.  (ctypes releases the GIL during libtrx calls.)
-    """
+
+def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0, dtype=torch.complex64,
+                      precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),), polarization="xx",
+                      direction="forward", port="transmission", check_info=True):
+    """B sweep points of a multi-layer stack (BASELINE.json configs 2-4): the reference's per-point Python loop
+    (example/Example1-1.ipynb, Example3.ipynb) as chunks of a batched solve.  `layers` as in `_solve_chunk`, with
+    per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)]."""
     import threading
     B = freq.shape[0]
     chunk = B if chunk is None else int(chunk)
@@ -91,15 +92,13 @@ def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, *, eps_in=Non
     spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
     outs = [None] * len(spans)
 
-    def th_of(lo, hi):
-        return thickness[lo:hi] if torch.is_tensor(thickness) and thickness.dim() > 0 else thickness
-
     def run(i):
         lo, hi = spans[i]
-        outs[i] = _solve_chunk(freq[lo:hi], eps_grids[lo:hi], th_of(lo, hi), order, L, eps_in, eps_out, inc_ang, azi_ang, dtype,
-                               precision, engine, orders, polarization, direction, port, check_info)
+        lays = [tuple(_slice(v, lo, hi, B) for v in lay) for lay in layers]
+        outs[i] = _solve_chunk(freq[lo:hi], lays, order, L, _slice(eps_in, lo, hi, B), _slice(eps_out, lo, hi, B), _slice(inc_ang, lo, hi, B),
+                               _slice(azi_ang, lo, hi, B), dtype, precision, engine, orders, polarization, direction, port, check_info)
 
-    dev = eps_grids.device
+    dev = freq.device
     if streams <= 1 or len(spans) == 1 or dev.type != "cuda":
         for i in range(len(spans)):
             run(i)
@@ -127,3 +126,13 @@ def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, *, eps_in=Non
         for st in pool:
             cur.wait_stream(st)
     return torch.cat(outs, dim=0)
+
+
+def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
+    """B sweep points of a 1-patterned-layer stack (configs 2 and 4 of BASELINE.json): freq [B], eps_grids [B,nx,ny].
+
+    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).
+    streams : number of HIP streams / host threads the chunks are dealt to (default 1: on MI355X one stream was measured
+              faster -- the QR window kernel needs 133 KB of LDS and evicts the slab workgroups of the other stream).
+    """
+    return solve_stack_sweep(freq.to(eps_grids.device), [(thickness, eps_grids)], order, L, **kw)
