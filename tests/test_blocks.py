@@ -37,7 +37,7 @@ def test_gemm(backend, dtype, tol, opA, opB):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
-@pytest.mark.parametrize("n,nrhs", [(5, 3), (32, 32), (33, 7), (97, 130), (150, 20), (290, 40)])
+@pytest.mark.parametrize("n,nrhs", [(5, 3), (32, 32), (33, 7), (97, 130), (150, 20), (290, 40), (530, 16)])
 def test_lu_solve(backend, dtype, tol, n, nrhs):
     be = get_backend(backend)
     batch = 2

@@ -187,10 +187,10 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 }  // namespace
 
 // Two-level blocking: panels of NB columns are factored one at a time, but the update of everything to the right of
-// the current OUTER block (NBO = 4 panels) is delayed until the whole outer block is done, so the dominant trailing
-// update is a rank-128 GEMM (compute-bound on the matrix cores) instead of four rank-32 updates (HBM-bound: each
+// the current OUTER block (NBO = 8 panels) is delayed until the whole outer block is done, so the dominant trailing
+// update is a rank-256 GEMM (compute-bound on the matrix cores) instead of four rank-32 updates (HBM-bound: each
 // re-reads and re-writes the trailing matrix).
-constexpr int NBO = 4 * NB;
+constexpr int NBO = 8 * NB;
 
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {

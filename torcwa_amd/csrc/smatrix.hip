@@ -113,6 +113,36 @@ __global__ __launch_bounds__(256) void block_copy_kernel(const cx<T>* __restrict
     dst[(long)b * sd + (long)i * ldd + j] = v;
 }
 
+// out[b] = in[b]^T  (n x n, tiled through LDS so that both the read and the write are coalesced)
+template <class T>
+__global__ __launch_bounds__(256) void transpose_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, int n) {
+    __shared__ cx<T> tile[32][33];
+    const long base = (long)blockIdx.z * n * n;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < n && c < n) tile[i][threadIdx.x] = in[base + (long)r * n + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = c0 + i, c = r0 + threadIdx.x;          // transposed block
+        if (r < n && c < n) out[base + (long)r * n + c] = tile[threadIdx.x][i];
+    }
+}
+
+// Rp = W (I + X), Rm = W (I - X)   (column scalings by the layer phase)
+template <class T>
+__global__ __launch_bounds__(256) void layer_R_kernel(const cx<T>* __restrict__ W, const cx<T>* __restrict__ x, int n, cx<T>* __restrict__ Rp, cx<T>* __restrict__ Rm) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long o = ((long)b * n + i) * n + j;
+    const cx<T> w = W[o], xj = x[(long)b * n + j];
+    const cx<T> wx = w * xj;
+    Rp[o] = w + wx;
+    Rm[o] = w - wx;
+}
+
 template <class T>
 int build_pq_t(hipStream_t s, const void* E, const void* Ei, const void* M, const void* Mi, const void* kx, const void* ky, int N, int batch, void* P, void* Q) {
     TRX_LAUNCH((build_pq_kernel<T>), dim3(cdiv_i(N, 256), N, batch), dim3(256), 0, s, (const cx<T>*)E, (const cx<T>*)Ei, (const cx<T>*)M, (const cx<T>*)Mi,
@@ -146,10 +176,25 @@ int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* 
     }
     const long bN = (long)batch * N;
     TRX_LAUNCH((layer_T_kernel<T>), dim3(cdiv_i(n, 256), N, batch), blk, 0, s, W, (const cx<T>*)V, pv, pv + bN, pv + 2 * bN, pv + 3 * bN, x, N, T2, T2 + bn);
+    int* piv2 = piv + (long)batch * n;               // caller provides 3*batch*n ints
+    int* info2 = info + batch;                       // and 3*batch info slots
+    if (!cp) {
+        // Coupling coefficients not requested: M+ = W(I+X) Tp^-1 and M- = W(I-X) Tm^-1 are RIGHT solves.  Done as left
+        // solves of the transposed systems (Tp^T M+^T = (W(I+X))^T): three O(n^2) tiled transposes replace the solve
+        // against the identity and both n^3 products of the explicit-inverse route (2.67 n^3 instead of 4.67 n^3 cMAC).
+        const dim3 tg(cdiv_i(n, 32), cdiv_i(n, 32), 2 * batch), tb(32, 8);
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, G, n);                         // G  = Tp^T | Tm^T
+        TRX_LAUNCH((layer_R_kernel<T>), g, blk, 0, s, W, x, n, Mx, Mx + bn);                             // Mx = W(I+X) | W(I-X)
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Mx, T2, n);                        // T2 = R+^T | R-^T
+        rc = lu_factor<T>(s, G, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
+        rc = lu_solve<T>(s, G, n, nn, n, piv2, T2, n, nn, n, 2 * batch); if (rc) return rc;              // T2 = M+^T | M-^T
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, Mx, n);                        // Mx = M+ | M-
+        TRX_LAUNCH((layer_S_kernel<T>), g, blk, 0, s, (const cx<T>*)Mx, (const cx<T>*)(Mx + bn), n, S11, S21);
+        TRX_CHECK_LAUNCH();
+        return TRX_OK;
+    }
     // invert Tp and Tm as one batch of 2B
     {
-        int* piv2 = piv + (long)batch * n;           // caller provides 3*batch*n ints
-        int* info2 = info + batch;                   // and 3*batch info slots
         rc = lu_factor<T>(s, T2, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
         TRX_LAUNCH((block_copy_kernel<T>), dim3(cdiv_i(n, 256), n, 2 * batch), blk, 0, s, (const cx<T>*)nullptr, n, nn, G, n, nn, n, n, T(0), 1);
         rc = lu_solve<T>(s, T2, n, nn, n, piv2, G, n, nn, n, 2 * batch); if (rc) return rc;
