@@ -86,15 +86,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(int m, int n, int k, cx<
         for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
 
     const int wave = t >> 6, lane = t & 63;
-    const int ntiles = (n - n0 >= BN) ? 4 : (n - n0 + 15) / 16;
     load_tiles(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
         store_tiles();
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
-        // skinny outputs (panel products of the LU / Hessenberg / trevc kernels): waves whose 16 rows, and column tiles
-        // whose 16 columns, lie entirely outside C issue no MFMAs
-        if (m0 + 16 * wave < m) cmma_tile_strided<T, 4>(Ar, Ai, sAr, sAk, 16 * wave, Br, Bi, sBk, sBc, 0, BK, accR, accI, ntiles);
+        cmma_tile_strided<T, 4>(Ar, Ai, sAr, sAk, 16 * wave, Br, Bi, sBk, sBc, 0, BK, accR, accI);
         __syncthreads();
     }
     const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));

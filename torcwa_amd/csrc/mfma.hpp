@@ -37,7 +37,7 @@ template <> struct Mfma<float> {
 template <class T, int NT>
 __device__ __forceinline__ void cmma_tile_strided(const T* __restrict__ Ar, const T* __restrict__ Ai, int sAr, int sAk, int arow0,
                                                   const T* __restrict__ Br, const T* __restrict__ Bi, int sBk, int sBc, int bcol0, int kcount,
-                                                  typename Mfma<T>::acc_t (&accR)[NT], typename Mfma<T>::acc_t (&accI)[NT], int ntiles = NT) {
+                                                  typename Mfma<T>::acc_t (&accR)[NT], typename Mfma<T>::acc_t (&accI)[NT]) {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int aoff = (arow0 + lr) * sAr + lk * sAk;
@@ -52,16 +52,17 @@ __device__ __forceinline__ void cmma_tile_strided(const T* __restrict__ Ar, cons
             br[j] = Br[boff + k0 * sBk + 16 * j * sBc];
             bi[j] = Bi[boff + k0 * sBk + 16 * j * sBc];
         }
-        // issue order keeps 2*NT independent MFMAs between two updates of the same accumulator;
-        // `ntiles` (wave-uniform) skips column tiles that lie entirely outside a narrow output
+        // issue order keeps 2*NT independent MFMAs between two updates of the same accumulator
+        // (no per-MFMA predicates here: conditional MFMAs make hipcc shuffle the whole accumulator file through
+        //  v_accvgpr_mov and quintuple the kernel time -- measured)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) if (j < ntiles) accR[j] = Mfma<T>::mma(ar, br[j], accR[j]);
+        for (int j = 0; j < NT; ++j) accR[j] = Mfma<T>::mma(ar, br[j], accR[j]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) if (j < ntiles) accI[j] = Mfma<T>::mma(ar, bi[j], accI[j]);
+        for (int j = 0; j < NT; ++j) accI[j] = Mfma<T>::mma(ar, bi[j], accI[j]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) if (j < ntiles) accR[j] = Mfma<T>::mma(nai, bi[j], accR[j]);
+        for (int j = 0; j < NT; ++j) accR[j] = Mfma<T>::mma(nai, bi[j], accR[j]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) if (j < ntiles) accI[j] = Mfma<T>::mma(ai, br[j], accI[j]);
+        for (int j = 0; j < NT; ++j) accI[j] = Mfma<T>::mma(ai, br[j], accI[j]);
     }
 }
 
