@@ -9,9 +9,10 @@
  *  - extern "C", plain pointers and sizes; no torch / HIP types.  `stream` is a hipStream_t passed as void*.
  *  - All matrices are row-major, interleaved complex (re,im), layout-identical to torch.complex64 / complex128;
  *    batched tensors are [batch, rows, cols] contiguous unless a leading dimension / stride is given.
- *  - All pointers are DEVICE pointers (HBM).  The library never allocates persistent memory, never synchronises
- *    the host and is stream-ordered and re-entrant: the caller owns every buffer including the workspace, whose
- *    size is returned by the matching *_ws_bytes() function.
+ *  - All pointers are DEVICE pointers (HBM).  The library never allocates device memory and is stream-ordered and
+ *    re-entrant: the caller owns every buffer including the workspace, whose size is returned by the matching
+ *    *_ws_bytes() function.  Every entry point is asynchronous EXCEPT trx_eig, whose QR iteration is convergence-driven:
+ *    it synchronises `stream` once per outer iteration to read back a 16-byte progress summary.
  *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
  *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
  */

@@ -31,21 +31,7 @@ struct Rot {
     cx<T> s, r;
 };
 
-// G = [[c, s], [-conj(s), c]] with G [f; g] = [r; 0]
-template <class T>
-__device__ __forceinline__ Rot<T> rotg(cx<T> f, cx<T> g) {
-    Rot<T> R;
-    const T ag = cabs(g);
-    if (ag == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
-    const T af = cabs(f);
-    if (af == T(0)) { R.c = T(0); R.s = (T(1) / ag) * conj(g); R.r = cx<T>(ag, T(0)); return R; }
-    const T d = hypot(af, ag);
-    const cx<T> ph = (T(1) / af) * f;
-    R.c = af / d;
-    R.s = (T(1) / d) * (ph * conj(g));
-    R.r = d * ph;
-    return R;
-}
+// Rotations G = [[c, s], [-conj(s), c]] (c real) with G [f; g] = [r; 0]; see rotg_fast below.
 // rows:  (x, y) <- (c x + s y, -conj(s) x + c y)
 template <class T>
 __device__ __forceinline__ void rot_rows(const Rot<T>& R, cx<T>& x, cx<T>& y) {

@@ -78,7 +78,7 @@ extern "C" int trx_prof_get(int tag, double* out) {
 }
 
 extern "C" const char* trx_prof_tag_name(int tag) {
-    static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "(unused)", "apply_window_kernel",
+    static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "(retired tag)", "apply_window_kernel",
                                             "qr_window_kernel", "hess_gemv_kernel"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }
