@@ -8,7 +8,8 @@ struct EigPlan {
     static constexpr int HNB = 32;     // Hessenberg panel width
     static constexpr int QW = 64;      // QR window size (rows/cols staged in LDS)
     static constexpr int QNS = 16;     // shifts (= bulges) per sweep, spaced 2 rows apart
-    static constexpr int QNMIN = 32;   // active blocks up to this size are finished by the in-LDS single-shift QR
+    static constexpr int QNMIN = 64;   // active blocks up to this size are finished by the in-LDS explicit-shift QR (one wave)
+    static constexpr int QAED = 64;    // aggressive-early-deflation window (<= QNMIN, <= 64: one lane per column)
     static constexpr int VNB = 32;     // block height of the triangular eigenvector back-substitution
 };
 
