@@ -304,7 +304,7 @@ def _swap_adjacent(T, V, k):
     V[:, k:k + 2] = V[:, k:k + 2] @ G.conj().T
 
 
-def aed_step(H, Z, ilo, ihi, nw):
+def aed_step(H, Z, ilo, ihi, nw, max_moves=None):
     """One AED on the trailing nw x nw window of the active block.  Returns (nd, shifts)."""
     n = H.shape[0]
     eps = np.finfo(np.float64).eps
@@ -318,6 +318,7 @@ def aed_step(H, Z, ilo, ihi, nw):
         return 0, np.diag(T).copy()
     ns = nw
     ilst = 0
+    moves = 0
     while ilst < ns:
         foo = abs(T[ns - 1, ns - 1].real) + abs(T[ns - 1, ns - 1].imag)
         if foo == 0:
@@ -326,9 +327,12 @@ def aed_step(H, Z, ilo, ihi, nw):
         if spike <= max(smlnum, eps * foo):
             ns -= 1                       # deflatable
         else:
+            if max_moves is not None and moves >= max_moves:
+                break                      # limited reordering: stop at the first undeflatable eigenvalue after max_moves
             for k in range(ns - 2, ilst - 1, -1):     # move it to position ilst
                 _swap_adjacent(T, V, k)
             ilst += 1
+            moves += 1
     if ns == 0:
         s = 0.0
     nd = nw - ns
@@ -356,7 +360,7 @@ def aed_step(H, Z, ilo, ihi, nw):
     return nd, np.diag(T)[:ns].copy()
 
 
-def multishift_qr_aed(H, Z, ns=4, w=16, nmin=12, nw=None, stats=None, nibble=14):
+def multishift_qr_aed(H, Z, ns=4, w=16, nmin=12, nw=None, stats=None, nibble=14, max_moves=None):
     """multishift_qr with an AED step before every sweep."""
     n = H.shape[0]
     eps = np.finfo(np.float64).eps
@@ -388,7 +392,7 @@ def multishift_qr_aed(H, Z, ns=4, w=16, nmin=12, nw=None, stats=None, nibble=14)
             ihi = ilo - 1
             continue
         aeds += 1
-        nd, shifts = aed_step(H, Z, ilo, ihi, nw)
+        nd, shifts = aed_step(H, Z, ilo, ihi, nw, max_moves)
         if nd > 0:
             stall = 0
             if nibble is None or nd * 100 >= nibble * min(nw, m):      # enough deflation: skip the sweep, AED again
