@@ -16,6 +16,8 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * N * EigPlan::HNB) * 2;                       // Vp, Yp
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Tp
     tot += al256(e * B * EigPlan::HNB * N) * 2;                       // W1, W2
+    tot += al256(e * B * N * 2 * EigPlan::HNB) * 2;                   // YV, BC
+    tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Sm
     tot += al256(e * B * EigPlan::HNB);                               // tau
     tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U
     tot += al256(e * B * EigPlan::QNS);                               // shifts
@@ -37,6 +39,9 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.Tp = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
     Bf.W1 = (cx<T>*)take(e * B * EigPlan::HNB * N);
     Bf.W2 = (cx<T>*)take(e * B * EigPlan::HNB * N);
+    Bf.YV = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
+    Bf.BC = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
+    Bf.Sm = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QNS);

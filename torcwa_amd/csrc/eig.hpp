@@ -36,6 +36,9 @@ struct EigBuffers {
     cx<T>* Tp;     // [B,HNB,HNB]
     cx<T>* W1;     // [B,HNB*n]
     cx<T>* W2;     // [B,HNB*n]
+    cx<T>* YV;     // [B,n,2*HNB]   [Y | V] operand of the fused trailing update
+    cx<T>* BC;     // [B,2*HNB,n]   [Vt^H ; T^H W]
+    cx<T>* Sm;     // [B,HNB,HNB]   V^H Y
     cx<T>* tau;    // [B,HNB]
     cx<T>* U;      // [B,QW,QW] window unitary
     cx<T>* shifts; // [B,QNS]

@@ -177,6 +177,24 @@ __global__ __launch_bounds__(256) void hess_gemv_kernel(const cx<T>* __restrict_
     }
 }
 
+// YV[r, 0:HNB] = Y[r,:], YV[r, HNB:2HNB] = V[r,:]   for rows r >= r0 (operand of the fused rank-2*HNB update)
+template <class T>
+__global__ __launch_bounds__(256) void pack_yv_kernel(const cx<T>* __restrict__ Yall, const cx<T>* __restrict__ Vall, cx<T>* __restrict__ YVall, int n, int r0) {
+    const int b = blockIdx.y;
+    const int r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (r >= n) return;
+    const cx<T>* src = (c < HNB) ? Yall : Vall;
+    YVall[((long)b * n + r) * 2 * HNB + c] = src[((long)b * n + r) * HNB + (c & (HNB - 1))];
+}
+// BC[c, j] = conj(V[row0 + j, c])   (first HNB rows of the [2*HNB, n]-strided operand of the fused update)
+template <class T>
+__global__ __launch_bounds__(256) void conj_transpose_panel_kernel(const cx<T>* __restrict__ Vall, cx<T>* __restrict__ BCall, int n, int row0, int mt) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mt) return;
+    BCall[(long)b * 2 * HNB * n + (long)c * n + j] = conj(Vall[((long)b * n + row0 + j) * HNB + c]);
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ X, int n) {
     cx<T>* M = X + (long)blockIdx.z * n * n;
@@ -220,12 +238,28 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
         rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, r0, nr, ib, mone, Y, HNB, sV, V + (long)r0 * HNB, HNB, sV, one, A + r0, n, nn, batch); if (rc) return rc;
         if (mt > 0) {
             cx<T>* At = A + (long)r0 * n + p0 + ib;           // A[R, p0+ib:n]
-            // (3) A[R, p0+ib:n] -= Y[R,:] V[p0+ib:n,:]^H
-            rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, nr, mt, ib, mone, Y + (long)r0 * HNB, HNB, sV, V + (long)(p0 + ib) * HNB, HNB, sV, one, At, n, nn, batch); if (rc) return rc;
-            // (4) W = V[R,:]^H A[R, p0+ib:n] ; (5) W2 = T^H W ; (6) A[R,..] -= V[R,:] W2
-            rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, nr, one, V + (long)r0 * HNB, HNB, sV, At, n, nn, zero, W, n, sW, batch); if (rc) return rc;
-            rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, ib, one, Tm, HNB, sT, W, n, sW, zero, W2, n, sW, batch); if (rc) return rc;
-            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nr, mt, ib, mone, V + (long)r0 * HNB, HNB, sV, W2, n, sW, one, At, n, nn, batch); if (rc) return rc;
+            if (ib == HNB) {
+                // Right and left block-reflector updates of the trailing block fused into ONE rank-2*HNB GEMM:
+                //   A <- A - Y Vt^H - V T^H W,   W = V^H (A - Y Vt^H) = V^H A - (V^H Y) Vt^H     (Vt = V[p0+ib:n,:])
+                //   =>  A <- A - [Y | V] [Vt^H ; T^H W]
+                // Three passes over the trailing block (read for V^H A, read+write for the update) instead of five.
+                const long sYV = (long)n * 2 * HNB, sBC = (long)2 * HNB * n;
+                cx<T>*YV = B.YV, *BC = B.BC, *Sm = B.Sm;
+                TRX_LAUNCH((pack_yv_kernel<T>), dim3(cdiv_i(nr, 4), batch), dim3(256), 0, s, (const cx<T>*)Y, (const cx<T>*)V, YV, n, r0);
+                TRX_LAUNCH((conj_transpose_panel_kernel<T>), dim3(cdiv_i(mt, 256), HNB, batch), dim3(256), 0, s, (const cx<T>*)V, BC, n, p0 + ib, mt);
+                rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, nr, one, V + (long)r0 * HNB, HNB, sV, At, n, nn, zero, W, n, sW, batch); if (rc) return rc;          // W0 = V^H A
+                rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, ib, nr, one, V + (long)r0 * HNB, HNB, sV, Y + (long)r0 * HNB, HNB, sV, zero, Sm, HNB, sT, batch); if (rc) return rc;   // S = V^H Y
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, ib, mt, ib, mone, Sm, HNB, sT, BC, n, sBC, one, W, n, sW, batch); if (rc) return rc;                        // W = W0 - S Vt^H
+                rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, ib, one, Tm, HNB, sT, W, n, sW, zero, BC + (long)HNB * n, n, sBC, batch); if (rc) return rc;          // T^H W
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nr, mt, 2 * HNB, mone, YV + (long)r0 * 2 * HNB, 2 * HNB, sYV, BC, n, sBC, one, At, n, nn, batch); if (rc) return rc;
+            } else {
+                // (3) A[R, p0+ib:n] -= Y[R,:] V[p0+ib:n,:]^H
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, nr, mt, ib, mone, Y + (long)r0 * HNB, HNB, sV, V + (long)(p0 + ib) * HNB, HNB, sV, one, At, n, nn, batch); if (rc) return rc;
+                // (4) W = V[R,:]^H A[R, p0+ib:n] ; (5) W2 = T^H W ; (6) A[R,..] -= V[R,:] W2
+                rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, nr, one, V + (long)r0 * HNB, HNB, sV, At, n, nn, zero, W, n, sW, batch); if (rc) return rc;
+                rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, ib, mt, ib, one, Tm, HNB, sT, W, n, sW, zero, W2, n, sW, batch); if (rc) return rc;
+                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nr, mt, ib, mone, V + (long)r0 * HNB, HNB, sV, W2, n, sW, one, At, n, nn, batch); if (rc) return rc;
+            }
         }
         // (7-9) Z[:, R] -= ((Z[:, R] V[R,:]) T) V[R,:]^H
         rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, ib, nr, one, Z + r0, n, nn, V + (long)r0 * HNB, HNB, sV, zero, W, HNB, sW, batch); if (rc) return rc;
