@@ -19,7 +19,7 @@ constexpr int LDM = 80;          // major-contiguous plane: element (major, k) a
 constexpr int PLANE = 1280;      // max(64*LDK, 16*LDM)
 
 template <class T, int OPA, int OPB>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
                                                         int ldc, long sC, const GemmDesc* __restrict__ desc) {
     __shared__ T Ar[PLANE];
