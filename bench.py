@@ -76,7 +76,7 @@ def roofline(engine, precision, elapsed):
         engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
         launches, timed, flops, nbytes, ms, flops_all = list(buf)
         tags.append({"kernel": engine.lib.prof_tag_name(tag).decode(), "launches": int(launches), "timed_launches": int(timed),
-                     "ms_timed": ms, "flops_timed": flops, "bytes_timed": nbytes})
+                     "ms_timed": ms, "flops_timed": flops, "bytes_timed": nbytes, "flops_all": flops_all})
     times = [{"kernel": t["kernel"], "launches": t["launches"], "timed_launches": t["timed_launches"],
               "avg_us": (1e3 * t["ms_timed"] / t["timed_launches"]) if t["timed_launches"] else None,
               "share_of_wall": (t["ms_timed"] * (t["launches"] / max(t["timed_launches"], 1)) / (1e3 * elapsed)) if t["timed_launches"] else None}
@@ -97,6 +97,12 @@ def roofline(engine, precision, elapsed):
             gbs = h["bytes_timed"] / (h["ms_timed"] * 1e-3) / 1e9
             roof["secondary"] = {"kernel": h["kernel"], "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * h["ms_timed"] / h["timed_launches"]}
+        a = tags[3]    # QR slab updates: the work is data dependent and counted on the device (all launches); time = avg of the timed launches
+        if a["timed_launches"] > 0 and a["ms_timed"] > 0 and a["flops_all"] > 0:
+            tf = a["flops_all"] / (a["ms_timed"] * 1e-3 * a["launches"] / a["timed_launches"]) / 1e12
+            roof["qr_slab_updates"] = {"kernel": a["kernel"], "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                                       "frac": tf / PEAK_TFLOPS[precision], "avg_launch_us": 1e3 * a["ms_timed"] / a["timed_launches"],
+                                       "note": "flops = 8 ww^2 (2n - ww) per matrix and window step, summed on the device over all launches"}
     return roof, times
 
 
@@ -111,6 +117,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of one extra (untimed) step, top entries to stderr")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -143,15 +150,29 @@ def main():
     # HIP-event timing of the dominant kernels, recorded by libtrx on the launch stream during the timed region
     engine.lib.prof_reset()
     engine.lib.prof_enable(1)
+    ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
     barrier()
     elapsed = time.perf_counter() - t0
     engine.lib.prof_enable(0)
+    ms1 = torch.cuda.memory_stats(device)
+    mem = {"peak_reserved_GB": ms1.get("reserved_bytes.all.peak", 0) / 1e9, "peak_allocated_GB": ms1.get("allocated_bytes.all.peak", 0) / 1e9,
+           "device_mallocs_in_timed_region": ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0),
+           "device_frees_in_timed_region": ms1.get("segment.all.freed", 0) - ms0.get("segment.all.freed", 0),
+           "alloc_retries": ms1.get("num_alloc_retries", 0)}
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
+    if args.host_profile and rank == 0:
+        import cProfile, pstats, sys
+        pr = cProfile.Profile()
+        pr.enable()
+        run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,7 +193,7 @@ def main():
             "config": {"workload": "configs[1]: single patterned layer, order=[%d,%d] (n=%d), 300x300 grid, %d-lambda sweep per GPU, "
                                    "glass input half-space" % (args.order, args.order, n, args.batch),
                        "batch_per_gpu": args.batch, "chunk": chunk, "streams": args.streams, "precision": args.precision},
-            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "numerical_failures": 0,
+            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "numerical_failures": 0, "hbm": mem,
         }
         res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed)
         if not args.no_cpu_baseline and world == 1:

@@ -51,6 +51,13 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+// streams execute synchronously in the emulator: extra streams and cross-stream waits are no-ops
+static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
@@ -252,6 +259,7 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
     return ::hipemu::wave_read<T>(s);
 }
 inline void __builtin_amdgcn_wave_barrier() { ::hipemu::wave_post<int>(0); }
+inline void __builtin_amdgcn_sched_barrier(int) {}      // compiler scheduling fence: nothing to emulate
 inline unsigned long long __ballot(int pred) {
     ::hipemu::wave_post<int>(pred ? 1 : 2);          // 2 = participated, false; 0 = stale/not participating
     unsigned long long m = 0;

@@ -84,3 +84,17 @@ def test_eig_degenerate_and_structured(backend):
         assert res < 1e-12
         assert match_eigs(w[b], np.linalg.eigvals(A[b])) < 1e-10
     assert np.linalg.cond(V[0]) < 1e6        # degenerate pairs must still give independent eigenvectors
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_two_iteration_groups(backend):
+    """batch >= 8 splits the QR phase into two groups on two streams (uneven halves here); matrices of very different
+    convergence speed (nearly diagonal, random, nearly triangular) make one group finish before the other."""
+    be = get_backend(backend)
+    n, batch = 70, 9
+    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
+    for b in range(0, 4):
+        A[b] = 1e-3 * A[b] + np.diag(np.arange(1, n + 1)).astype(np.complex128)      # group 0: nearly diagonal
+    A[8] = np.triu(A[8]) + 1e-6 * A[7] + np.diag(2.0 * np.arange(n))
+    w, V, info = run_eig(be, A)
+    check(A, w, V, info, 1e-12)

@@ -44,7 +44,7 @@ extern "C" int trx_gemm(int dtype, int opA, int opB, int m, int n, int k, const 
                         long strideC, int batch, void* stream) {
     if (!alpha || !beta || !A || !B || !C) return TRX_ERR_ARG;
     if (m < 0 || n < 0 || k < 0 || batch < 0) return TRX_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64)
         return gemm<float>(s, opA, opB, m, n, k, *(const cx<float>*)alpha, (const cx<float>*)A, lda, strideA, (const cx<float>*)B,
                            ldb, strideB, *(const cx<float>*)beta, (cx<float>*)C, ldc, strideC, batch);
@@ -56,7 +56,7 @@ extern "C" int trx_gemm(int dtype, int opA, int opB, int m, int n, int k, const 
 
 extern "C" int trx_lu_solve(int dtype, void* A, int n, void* B, int nrhs, int batch, int* piv, int* info, void* stream) {
     if (!A || !B || !piv || !info || n < 0 || nrhs < 0 || batch < 0) return TRX_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     const long nn = (long)n * n, nr = (long)n * nrhs;
     if (dtype == TRX_C64) {
         int rc = lu_factor<float>(s, (cx<float>*)A, n, nn, n, piv, batch, info);
@@ -76,7 +76,7 @@ extern "C" size_t trx_inverse_ws_bytes(int dtype, int n, int batch) {
 extern "C" int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
     if (!A || !piv || !info || !ws || n < 0 || batch < 0) return TRX_ERR_ARG;
     if (ws_bytes < trx_inverse_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return inverse_t<float>(s, (cx<float>*)A, n, batch, piv, info, (cx<float>*)ws);
     if (dtype == TRX_C128) return inverse_t<double>(s, (cx<double>*)A, n, batch, piv, info, (cx<double>*)ws);
     return TRX_ERR_DTYPE;

@@ -1,5 +1,6 @@
 // Shared device/host helpers for libtrx (MI355X / gfx950 RCWA layer-solve kernels).
 #pragma once
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -111,8 +112,18 @@ static inline int set_max_dyn_smem(const void* kernel, size_t bytes) {
 #define TRX_CHECK_LAUNCH()                                  \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \
-        if (e__ != hipSuccess) return TRX_ERR_LAUNCH;       \
+        if (e__ != hipSuccess) {                            \
+            fprintf(stderr, "libtrx: HIP error '%s' at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return TRX_ERR_LAUNCH;                          \
+        }                                                   \
     } while (0)
+
+// Entry of every extern "C" function: clears a stale sticky error of the calling thread (e.g. hipErrorNotReady left behind by
+// an event or stream query of the host framework) so that TRX_CHECK_LAUNCH reports only errors of this library's own calls.
+inline hipStream_t api_stream(void* stream) {
+    (void)hipGetLastError();
+    return (hipStream_t)stream;
+}
 
 // ---- internal entry points (defined across the .hip files) -------------------------------------------
 struct GemmDesc {            // optional per-batch override (device array), used by the eigensolver

@@ -113,7 +113,7 @@ extern "C" int trx_convmat(int dtype, int grid_is_complex, const void* grid, int
     if (batch <= 0 || ox < 0 || oy < 0 || nx <= 2 * ox || ny <= 2 * oy) return TRX_ERR_ARG;
     if (ws_bytes < trx_convmat_ws_bytes(dtype, batch, nx, ny, ox, oy)) return TRX_ERR_WORKSPACE;
     if ((size_t)16 * 2 * (size_t)(nx > ny ? nx : ny) > 64 * 1024) return TRX_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return trx::convmat_t<float>(grid_is_complex, grid, batch, nx, ny, ox, oy, out, ws, s);
     if (dtype == TRX_C128) return trx::convmat_t<double>(grid_is_complex, grid, batch, nx, ny, ox, oy, out, ws, s);
     return TRX_ERR_DTYPE;

@@ -22,7 +22,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U
     tot += al256(e * B * EigPlan::QNS);                               // shifts
     tot += al256(sizeof(QrState) * B);
-    tot += al256(sizeof(int) * 4);
+    tot += al256(sizeof(int) * 64);
     return tot;
 }
 
@@ -46,7 +46,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QNS);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
-    Bf.summary = (int*)take(sizeof(int) * 4);
+    Bf.summary = (int*)take(sizeof(int) * 64);   // up to 8 iteration groups x 8 ints
 }
 
 namespace {
@@ -89,6 +89,6 @@ extern "C" int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, i
     if (!A || !w || !V || !info || !ws || n <= 0 || batch <= 0) return TRX_ERR_ARG;
     if (dtype != TRX_C64 && dtype != TRX_C128) return TRX_ERR_DTYPE;
     if (ws_bytes < trx_eig_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     return dtype == TRX_C128 ? trx::eig_t<double>(s, A, w, V, n, batch, info, ws) : trx::eig_t<float>(s, A, w, V, n, batch, info, ws);
 }

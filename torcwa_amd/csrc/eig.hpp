@@ -43,7 +43,7 @@ struct EigBuffers {
     cx<T>* U;      // [B,QW,QW] window unitary
     cx<T>* shifts; // [B,QNS]
     QrState* st;   // [B]
-    int* summary;  // [4]
+    int* summary;  // [64]: 8 ints per iteration group of the QR phase (up to 8 groups)
 };
 
 template <class T> size_t eig_ws_bytes_t(int n, int batch);

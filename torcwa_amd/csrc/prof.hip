@@ -44,6 +44,12 @@ void prof_end(int tag, int slot, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_mu);
     hipEventRecord(g_tags[tag].stop[slot], s);
 }
+
+void prof_add_work(int tag, double flops, double bytes) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_tags[tag].flops += flops;
+    g_tags[tag].bytes += bytes;
+}
 }  // namespace trx
 
 using namespace trx;

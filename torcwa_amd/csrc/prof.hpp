@@ -12,6 +12,8 @@ bool prof_enabled();
 // returns an event-slot handle (>= 0) or -1 when disabled / pool exhausted; records the start event
 int prof_begin(int tag, hipStream_t s, double flops, double bytes);
 void prof_end(int tag, int slot, hipStream_t s);
+// adds algorithmic work that is only known after the launches ran (data-dependent kernels count it on the device)
+void prof_add_work(int tag, double flops, double bytes);
 
 struct ProfScope {
     int tag, slot;

@@ -402,7 +402,7 @@ using namespace trx;
 extern "C" int trx_build_pq(int dtype, const void* E, const void* Einv, const void* Mu, const void* Muinv, const void* kx,
                             const void* ky, int N, int batch, void* P, void* Q, void* stream) {
     if (!E || !Einv || !Mu || !Muinv || !kx || !ky || !P || !Q || N <= 0 || batch <= 0) return TRX_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return build_pq_t<float>(s, E, Einv, Mu, Muinv, kx, ky, N, batch, P, Q);
     if (dtype == TRX_C128) return build_pq_t<double>(s, E, Einv, Mu, Muinv, kx, ky, N, batch, P, Q);
     return TRX_ERR_DTYPE;
@@ -419,7 +419,7 @@ extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const 
     if ((use_q && !Q) || (!use_q && !P)) return TRX_ERR_ARG;
     if ((Cplus == nullptr) != (Cminus == nullptr)) return TRX_ERR_ARG;
     if (ws_bytes < trx_layer_smatrix_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64)
         return layer_smatrix_t<float>(s, (const cx<float>*)P, (const cx<float>*)Q, (const cx<float>*)W, (const cx<float>*)kzfac, (const cx<float>*)vfinv,
                                       (const cx<float>*)phase, use_q, N, batch, (cx<float>*)S11, (cx<float>*)S21, (cx<float>*)V, (cx<float>*)Cplus,
@@ -441,7 +441,7 @@ extern "C" int trx_redheffer(int dtype, const void* const* Sm, const void* const
     for (int k = 0; k < 4; ++k)
         if (!Sm[k] || !Sn[k] || !Sout[k]) return TRX_ERR_ARG;
     if (ws_bytes < trx_redheffer_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return redheffer_t<float>(s, (const cx<float>* const*)Sm, (const cx<float>* const*)Sn, (cx<float>* const*)Sout, (cx<float>*)XY, n, batch, piv, info, (cx<float>*)ws);
     if (dtype == TRX_C128) return redheffer_t<double>(s, (const cx<double>* const*)Sm, (const cx<double>* const*)Sn, (cx<double>* const*)Sout, (cx<double>*)XY, n, batch, piv, info, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
@@ -453,7 +453,7 @@ extern "C" int trx_redheffer_halfspace(int dtype, int side, const void* bd, cons
     for (int k = 0; k < 4; ++k)
         if (!S[k] || !Sout[k]) return TRX_ERR_ARG;
     if (ws_bytes < trx_redheffer_ws_bytes(dtype, 2 * N, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return redheffer_halfspace_t<float>(s, side, (const cx<float>*)bd, (const cx<float>* const*)S, (cx<float>* const*)Sout, (cx<float>*)XY, N, batch, piv, info, (cx<float>*)ws);
     if (dtype == TRX_C128) return redheffer_halfspace_t<double>(s, side, (const cx<double>*)bd, (const cx<double>* const*)S, (cx<double>* const*)Sout, (cx<double>*)XY, N, batch, piv, info, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
@@ -467,7 +467,7 @@ extern "C" int trx_build_a(int dtype, const void* E, const void* Einv, const voi
                            void* ws, size_t ws_bytes, void* stream) {
     if (!E || !Einv || !mu || !kx || !ky || !A || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
     if (ws_bytes < trx_build_a_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return build_a_t<float>(s, (const cx<float>*)E, (const cx<float>*)Einv, (const cx<float>*)mu, (const cx<float>*)kx, (const cx<float>*)ky, N, batch, (cx<float>*)A, (cx<float>*)ws);
     if (dtype == TRX_C128) return build_a_t<double>(s, (const cx<double>*)E, (const cx<double>*)Einv, (const cx<double>*)mu, (const cx<double>*)kx, (const cx<double>*)ky, N, batch, (cx<double>*)A, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
