@@ -99,7 +99,11 @@ int trx_redheffer(int dtype, const void* const* Sm, const void* const* Sn, void*
 /* Star product with a HALF-SPACE operand (the Sin / Sout coupling steps of solve_global_smatrix, rcwa.py:198-208).
  * The four blocks of Sin / Sout are 2x2-block-diagonal (rcwa.py:1157-1181), so they are passed as diagonals
  * bd[4 blocks S11,S21,S12,S22][4 diagonals d11,d12,d21,d22][batch][N] and every product with them is O(n^2).
- * side = 0: half-space on the left (Sin * S);  side = 1: on the right (S * Sout).  Other arguments as trx_redheffer. */
+ * side = 0: half-space on the left (Sin * S);  side = 1: on the right (S * Sout).  Other arguments as trx_redheffer.
+ * XY may be NULL for side = 0 when the coupling factors are not needed (no C lists to propagate): the product is then
+ * formed with right-solves (4.33 n^3 instead of 6.33 n^3 complex MACs) and needs the larger workspace reported by
+ * trx_redheffer_halfspace_ws_bytes(dtype, N, batch, side, want_xy = 0). */
+size_t trx_redheffer_halfspace_ws_bytes(int dtype, int N, int batch, int side, int want_xy);
 int trx_redheffer_halfspace(int dtype, int side, const void* bd, const void* const* S, void* const* Sout, void* XY, int N, int batch,
                             int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
 

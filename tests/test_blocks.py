@@ -136,3 +136,47 @@ def test_convmat_rejects_small_grid(backend):
     g, out = be.dev(np.zeros((1, 6, 6))), be.empty((1, 49, 49), np.complex128)
     ws = be.empty((1 << 16,), np.uint8)
     assert be.lib.convmat(1, 0, be.ptr(g), 1, 6, 6, 3, 3, be.ptr(out), be.ptr(ws), 1 << 16, be.stream) == -2
+
+
+def _bd_dense(d):
+    """[4 diagonals d11,d12,d21,d22][N] -> dense 2N x 2N block-diagonal operator."""
+    return np.block([[np.diag(d[0]), np.diag(d[1])], [np.diag(d[2]), np.diag(d[3])]])
+
+
+def _star(Sm, Sn):
+    """Redheffer star product, the reference's formulas (torcwa/rcwa.py:1287-1296), blocks ordered [S11,S21,S12,S22]."""
+    n = Sm[0].shape[0]
+    I = np.eye(n)
+    t1 = np.linalg.inv(I - Sm[2] @ Sn[1])
+    t2 = np.linalg.inv(I - Sn[1] @ Sm[2])
+    return [Sn[0] @ t1 @ Sm[0], Sm[1] + Sm[3] @ t2 @ Sn[1] @ Sm[0], Sn[2] + Sn[0] @ t1 @ Sm[2] @ Sn[3], Sm[3] @ t2 @ Sn[3]]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-4)])
+@pytest.mark.parametrize("side,want_xy", [(0, 1), (0, 0), (1, 1)])
+def test_redheffer_halfspace(backend, dtype, tol, side, want_xy):
+    """trx_redheffer_halfspace against the dense star product: both sides, and the lean side-0 path without coupling factors."""
+    be = get_backend(backend)
+    N, batch = 37, 2
+    n = 2 * N
+    bd = 0.4 * crand((4, 4, batch, N), dtype)
+    S = [0.3 * crand((batch, n, n), dtype) for _ in range(4)]
+    dbd, dS = be.dev(bd), [be.dev(x) for x in S]
+    out = [be.empty((batch, n, n), dtype) for _ in range(4)]
+    XY = be.empty((2, batch, n, 2 * n), dtype) if want_xy else None
+    piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+    nws = be.lib.redheffer_halfspace_ws_bytes(dtcode(dtype), N, batch, side, want_xy)
+    ws = be.empty((nws,), np.uint8)
+    import ctypes
+    arr = ctypes.c_void_p * 4
+    ps, po = arr(*[be.ptr(x) for x in dS]), arr(*[be.ptr(x) for x in out])
+    rc = be.lib.redheffer_halfspace(dtcode(dtype), side, be.ptr(dbd), ctypes.addressof(ps), ctypes.addressof(po), be.ptr(XY) if want_xy else None,
+                                    N, batch, be.ptr(piv), be.ptr(info), be.ptr(ws), nws, be.stream)
+    assert rc == 0 and (be.host(info) == 0).all()
+    for b in range(batch):
+        D = [_bd_dense(bd[k, :, b].astype(np.complex128)) for k in range(4)]
+        Sd = [x[b].astype(np.complex128) for x in S]
+        ref = _star(D, Sd) if side == 0 else _star(Sd, D)
+        for k in range(4):
+            assert np.abs(be.host(out[k])[b] - ref[k]).max() / np.abs(ref[k]).max() < tol, (side, want_xy, k)

@@ -31,6 +31,7 @@ _SIGS = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_redheffer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_redheffer": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "trx_redheffer_halfspace_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "trx_redheffer_halfspace": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_build_a_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_build_a": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -351,7 +351,7 @@ class BatchedRCWA:
             dense = [blk.dense().to(self._cdtype) for blk in Sbd]
             return self._RS_prod_diff(dense, S, [[], []], C) if side == 0 else self._RS_prod_diff(S, dense, C, [[], []])
         bd = torch.stack([torch.stack(blk.d, dim=0) for blk in Sbd], dim=0).to(self._cdtype).contiguous()   # [4,4,B,N]
-        Sn, X1, X2, Y1, Y2 = eng.redheffer_halfspace(side, bd, S)
+        Sn, X1, X2, Y1, Y2 = eng.redheffer_halfspace(side, bd, S, want_xy=len(C[0]) > 0)
         Cn = [[], []]
         if side == 0:                       # C belongs to the right operand (rcwa.py:1302-1304)
             for k in range(len(C[0])):

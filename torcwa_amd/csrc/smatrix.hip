@@ -113,20 +113,22 @@ __global__ __launch_bounds__(256) void block_copy_kernel(const cx<T>* __restrict
     dst[(long)b * sd + (long)i * ldd + j] = v;
 }
 
-// out[b] = in[b]^T  (n x n, tiled through LDS so that both the read and the write are coalesced)
+// out[b] = in[b]^T  (n x n blocks with leading dimensions ldi / ldo and batch strides si / so; tiled through LDS so that
+// both the read and the write are coalesced)
 template <class T>
-__global__ __launch_bounds__(256) void transpose_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, int n) {
+__global__ __launch_bounds__(256) void transpose_kernel(const cx<T>* __restrict__ in, int ldi, long si, cx<T>* __restrict__ out, int ldo, long so, int n) {
     __shared__ cx<T> tile[32][33];
-    const long base = (long)blockIdx.z * n * n;
+    in += (long)blockIdx.z * si;
+    out += (long)blockIdx.z * so;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
-        if (r < n && c < n) tile[i][threadIdx.x] = in[base + (long)r * n + c];
+        if (r < n && c < n) tile[i][threadIdx.x] = in[(long)r * ldi + c];
     }
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = c0 + i, c = r0 + threadIdx.x;          // transposed block
-        if (r < n && c < n) out[base + (long)r * n + c] = tile[threadIdx.x][i];
+        if (r < n && c < n) out[(long)r * ldo + c] = tile[threadIdx.x][i];
     }
 }
 
@@ -183,12 +185,12 @@ int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* 
         // solves of the transposed systems (Tp^T M+^T = (W(I+X))^T): three O(n^2) tiled transposes replace the solve
         // against the identity and both n^3 products of the explicit-inverse route (2.67 n^3 instead of 4.67 n^3 cMAC).
         const dim3 tg(cdiv_i(n, 32), cdiv_i(n, 32), 2 * batch), tb(32, 8);
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, G, n);                         // G  = Tp^T | Tm^T
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, n, nn, G, n, nn, n);                         // G  = Tp^T | Tm^T
         TRX_LAUNCH((layer_R_kernel<T>), g, blk, 0, s, W, x, n, Mx, Mx + bn);                             // Mx = W(I+X) | W(I-X)
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Mx, T2, n);                        // T2 = R+^T | R-^T
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Mx, n, nn, T2, n, nn, n);                        // T2 = R+^T | R-^T
         rc = lu_factor<T>(s, G, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
         rc = lu_solve<T>(s, G, n, nn, n, piv2, T2, n, nn, n, 2 * batch); if (rc) return rc;              // T2 = M+^T | M-^T
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, Mx, n);                        // Mx = M+ | M-
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, n, nn, Mx, n, nn, n);                        // Mx = M+ | M-
         TRX_LAUNCH((layer_S_kernel<T>), g, blk, 0, s, (const cx<T>*)Mx, (const cx<T>*)(Mx + bn), n, S11, S21);
         TRX_CHECK_LAUNCH();
         return TRX_OK;
@@ -306,7 +308,42 @@ int redheffer_halfspace_t(hipStream_t s, int side, const cx<T>* bd, const cx<T>*
     cx<T>* X = XY;                 // [B,n,2n]  X1 | X2
     cx<T>* Y = XY + 2 * bn;        // [B,n,2n]  Y1 | Y2
     int rc;
-    if (side == 0) {
+    if (side == 0 && !XY) {
+        // Coupling factors not requested: with D = half-space blocks, K = I - D12 Sn21, T1 = Sn11 K^-1, T2 = Sn21 K^-1 (RIGHT solves,
+        // done as one left solve of the transposed system with 2n right-hand sides) and M = D12 Sn22:
+        //   S11 = T1 D11,   S12 = Sn12 + T1 M,   S21 = D21 + D22 T2 D11,   S22 = D22 (Sn22 + T2 M)
+        // (push-through: (I - Sn21 D12)^-1 = I + T2 D12).  One LU, one 2n-column solve, two n^3 products = 4.33 n^3 complex MACs
+        // instead of 6.33; every other step is an O(n^2) combination with block-diagonal factors or a tiled transpose.
+        cx<T>* Kt = ws + bn;           // [B,n,n]
+        cx<T>* Xs = ws + 2 * bn;       // [B,n,2n]  [Sn11^T | Sn21^T] -> solution; later two [B,n,n] temporaries
+        cx<T>* Ys = ws + 4 * bn;       // [B,n,2n]  [T1 | T2]
+        const dim3 tg(cdiv_i(n, 32), cdiv_i(n, 32), batch), tb(32, 8);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[1], n, nn, (const cx<T>*)nullptr, 0, 0L, K, n, nn, N, n, T(-1), 1);
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)K, n, nn, Kt, n, nn, n);
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, S[0], n, nn, Xs, 2 * n, 2 * nn, n);
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, S[1], n, nn, Xs + n, 2 * n, 2 * nn, n);
+        rc = lu_factor<T>(s, Kt, n, nn, n, piv, batch, info); if (rc) return rc;
+        rc = lu_solve<T>(s, Kt, n, nn, n, piv, Xs, 2 * n, 2 * nn, 2 * n, batch); if (rc) return rc;
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Xs, 2 * n, 2 * nn, Ys, 2 * n, 2 * nn, n);
+        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)(Xs + n), 2 * n, 2 * nn, Ys + n, 2 * n, 2 * nn, n);
+        cx<T>* M = K;                  // K is no longer needed (its transpose was factored)
+        cx<T>* Ta = Xs;                // [B,n,n] temporaries in the solve buffer
+        cx<T>* Tb = Xs + bn;
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[3], n, nn, (const cx<T>*)nullptr, 0, 0L, M, n, nn, N, n, T(1), 0);
+        // S11 = T1 D11
+        TRX_LAUNCH((bd_colcomb_kernel<T>), gc, blk, 0, s, D11, bN, (const cx<T>*)Ys, 2 * n, 2 * nn, O[0], n, nn, N, n, T(1), 0);
+        // S12 = Sn12 + T1 M
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[2], n, nn, O[2], n, nn, n, n, T(1), 0);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Ys, 2 * n, 2 * nn, M, n, nn, one, O[2], n, nn, batch); if (rc) return rc;
+        // S21 = D21 + D22 (T2 D11)
+        TRX_LAUNCH((bd_colcomb_kernel<T>), gc, blk, 0, s, D11, bN, (const cx<T>*)(Ys + n), 2 * n, 2 * nn, Ta, n, nn, N, n, T(1), 0);
+        TRX_LAUNCH((bd_dense_kernel<T>), gn, blk, 0, s, D21, bN, (const cx<T>*)nullptr, 0, 0L, O[1], n, nn, N);
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D22, bN, (const cx<T>*)Ta, n, nn, (const cx<T>*)O[1], n, nn, O[1], n, nn, N, n, T(1), 0);
+        // S22 = D22 (Sn22 + T2 M)
+        TRX_LAUNCH((block_copy_kernel<T>), gn, blk, 0, s, S[3], n, nn, Tb, n, nn, n, n, T(1), 0);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Ys + n, 2 * n, 2 * nn, M, n, nn, one, Tb, n, nn, batch); if (rc) return rc;
+        TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D22, bN, (const cx<T>*)Tb, n, nn, (const cx<T>*)nullptr, 0, 0L, O[3], n, nn, N, n, T(1), 0);
+    } else if (side == 0) {
         // Sm = half-space (block diagonal), Sn = S (dense)
         // K = I - Sm12 Sn21 ;  RHS = [Sm11 | Sm12 Sn22]
         TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[1], n, nn, (const cx<T>*)nullptr, 0, 0L, K, n, nn, N, n, T(-1), 1);
@@ -447,12 +484,18 @@ extern "C" int trx_redheffer(int dtype, const void* const* Sm, const void* const
     return TRX_ERR_DTYPE;
 }
 
+extern "C" size_t trx_redheffer_halfspace_ws_bytes(int dtype, int N, int batch, int side, int want_xy) {
+    const size_t nn = (size_t)(dtype == TRX_C128 ? 16 : 8) * (size_t)batch * (size_t)(2 * N) * (size_t)(2 * N);
+    return (side == 0 && !want_xy) ? 6 * nn : nn;
+}
+
 extern "C" int trx_redheffer_halfspace(int dtype, int side, const void* bd, const void* const* S, void* const* Sout, void* XY, int N, int batch,
                                        int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
-    if (!bd || !S || !Sout || !XY || !piv || !info || !ws || N <= 0 || batch <= 0 || (side != 0 && side != 1)) return TRX_ERR_ARG;
+    if (!bd || !S || !Sout || !piv || !info || !ws || N <= 0 || batch <= 0 || (side != 0 && side != 1)) return TRX_ERR_ARG;
+    if (!XY && side == 1) return TRX_ERR_ARG;            // the side-1 algebra produces the factors anyway: XY is its scratch
     for (int k = 0; k < 4; ++k)
         if (!S[k] || !Sout[k]) return TRX_ERR_ARG;
-    if (ws_bytes < trx_redheffer_ws_bytes(dtype, 2 * N, batch)) return TRX_ERR_WORKSPACE;
+    if (ws_bytes < trx_redheffer_halfspace_ws_bytes(dtype, N, batch, side, XY != nullptr)) return TRX_ERR_WORKSPACE;
     hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64) return redheffer_halfspace_t<float>(s, side, (const cx<float>*)bd, (const cx<float>* const*)S, (cx<float>* const*)Sout, (cx<float>*)XY, N, batch, piv, info, (cx<float>*)ws);
     if (dtype == TRX_C128) return redheffer_halfspace_t<double>(s, side, (const cx<double>*)bd, (const cx<double>* const*)S, (cx<double>* const*)Sout, (cx<double>*)XY, N, batch, piv, info, (cx<double>*)ws);

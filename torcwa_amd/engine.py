@@ -188,24 +188,28 @@ class Engine:
         return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
 
 
-    def redheffer_halfspace(self, side, bd, S):
+    def redheffer_halfspace(self, side, bd, S, want_xy=True):
         """Star product with a block-diagonal half-space S-matrix (side 0: Sin * S, side 1: S * Sout).
-        bd: [4,4,B,N] diagonals (see include/trx.h)."""
+        bd: [4,4,B,N] diagonals (see include/trx.h).  want_xy=False (no coupling lists to propagate) lets side 0 use the
+        cheaper right-solve algebra; the factor slots of the result are then None."""
         S = [self._c(t) for t in S]
         B, n, _ = S[0].shape
         N = n // 2
         dt = S[0].dtype
         bd = self._c(bd.to(dt))
         out = [torch.empty((B, n, n), dtype=dt, device=self.device) for _ in range(4)]
-        XY = torch.empty((2, B, n, 2 * n), dtype=dt, device=self.device)
+        lean = (int(side) == 0) and not want_xy
+        XY = None if lean else torch.empty((2, B, n, 2 * n), dtype=dt, device=self.device)
         piv, info = self._ints(B * n), self._ints(B)
-        nws = self.lib.redheffer_ws_bytes(_CODE[dt], n, B)
+        nws = self.lib.redheffer_halfspace_ws_bytes(_CODE[dt], N, B, int(side), 0 if lean else 1)
         ws = self._ws(nws)
         arr = ctypes.c_void_p * 4
         ps, po = arr(*[t.data_ptr() for t in S]), arr(*[t.data_ptr() for t in out])
-        self.lib.check(self.lib.redheffer_halfspace(_CODE[dt], int(side), bd.data_ptr(), ctypes.addressof(ps), ctypes.addressof(po), XY.data_ptr(),
-                                                    N, B, piv.data_ptr(), info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self.lib.check(self.lib.redheffer_halfspace(_CODE[dt], int(side), bd.data_ptr(), ctypes.addressof(ps), ctypes.addressof(po),
+                                                    None if lean else XY.data_ptr(), N, B, piv.data_ptr(), info.data_ptr(), ws.data_ptr(), nws, self.stream))
         self._info(info, "redheffer_halfspace")
+        if lean:
+            return out, None, None, None, None
         X, Y = XY[0], XY[1]
         return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
 
