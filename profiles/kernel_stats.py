@@ -47,7 +47,7 @@ def by_grid(path, pattern, top=40):
         print(f"{k[0]:40s} {str(k[1:]):>20s} {a[0]:7d} {a[1] / 1e6:10.1f} {a[1] / a[0] / 1e3:10.1f} {100 * a[1] / tot:6.1f}%")
 
 
-PHASES = [("hessenberg", ("hess_",)), ("qr", ("qr_prepare", "qr_window", "apply_window", "qr_init")),
+PHASES = [("hessenberg", ("hess_", "pack_yv", "conj_transpose_panel", "set_identity")), ("qr", ("qr_prepare", "qr_window", "apply_window", "qr_init")),
           ("schur_vectors", ("trevc", "colnorm"))]
 
 
