@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
 
     const int wave = t >> 6, lane = t & 63;
+    const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
+    const int col_l = lane & 15;
     load_tiles(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
         store_tiles();
@@ -94,8 +96,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         cmma_tile_strided<T, 4>(Ar, Ai, sAr, sAk, 16 * wave, Br, Bi, sBk, sBc, 0, BK, accR, accI);
         __syncthreads();
     }
-    const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
-    const int col_l = lane & 15;
+    // C tile of this lane (beta != 0): all 16 loads are issued back to back with clamped addresses (the guards sit at the
+    // store), so a rank-32/64 update pays the read latency of C once instead of once per element behind an exec branch.
+    cx<T> cv[4][4];
+    if (has_beta) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * wave + Mfma<T>::crow(lane, r);
+            const int rc = row < m ? row : m - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + 16 * j + col_l;
+                cv[r][j] = C[(long)rc * ldc + (col < n ? col : n - 1)];
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + 16 * wave + Mfma<T>::crow(lane, r);
@@ -105,9 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
             const int col = n0 + 16 * j + col_l;
             if (col >= n) continue;
             cx<T> v = alpha * cx<T>(accR[j][r], accI[j][r]);
-            cx<T>* p = C + (long)row * ldc + col;
-            if (has_beta) v += beta * (*p);
-            *p = v;
+            if (has_beta) v += beta * cv[r][j];
+            C[(long)row * ldc + col] = v;
         }
     }
 }
