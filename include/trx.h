@@ -12,7 +12,9 @@
  *  - All pointers are DEVICE pointers (HBM).  The library never allocates device memory and is stream-ordered and
  *    re-entrant: the caller owns every buffer including the workspace, whose size is returned by the matching
  *    *_ws_bytes() function.  Every entry point is asynchronous EXCEPT trx_eig, whose QR iteration is convergence-driven:
- *    it synchronises `stream` once per outer iteration to read back a 16-byte progress summary.
+ *    it synchronises `stream` once per outer iteration to read back a 16-byte progress summary, and for batch >= 8 it
+ *    runs the QR phase of 2-4 sub-batches on internal non-blocking streams (forked from and joined back into `stream`
+ *    with events, created and destroyed inside the call) so that their latency-bound steps overlap.
  *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
  *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
  */
@@ -62,7 +64,8 @@ int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* info, void*
 /* ---- eigendecomposition: torcwa/torch_eig.py:12-17 (`Eig.forward` -> torch.linalg.eig), rcwa.py:1236/1238 -----
  * A [batch,n,n] general complex, DESTROYED.  w [batch,n] eigenvalues, V [batch,n,n] right eigenvectors in the
  * COLUMNS of V (A V = V diag(w)), each column scaled to unit 2-norm (LAPACK geev convention).  Order of the
- * eigenpairs is unspecified (as in LAPACK).  info[b] = 0 ok, >0: number of eigenvalues that failed to converge. */
+ * eigenpairs is unspecified (as in LAPACK).  info[b] = 0 ok, >0: number of eigenvalues that failed to converge.
+ * Size limit: n*n*sizeof(element) < 4 GiB (n < 16384 for complex128), else TRX_ERR_ARG. */
 size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
