@@ -80,12 +80,21 @@ int trx_build_pq(int dtype, const void* E, const void* Einv, const void* Mu, con
 /* ---- layer scattering matrix: torcwa/rcwa.py:1244-1281 (`_solve_layer_smatrix`) --------------------------------
  * Inputs  W [batch,n,n] eigenvectors (E_eigvec), n = 2N;
  *         kzfac [batch,n]: kz (use_q=0: V = P^-1 W diag(kz), rcwa.py:1264) or 1/kz (use_q=1: V = Q W diag(1/kz), :1262);
+ *         use_q=2: V is an INPUT (already computed, e.g. by trx_hmodes); P, Q and kzfac are not read;
  *         vfinv [4,batch,N]: the four diagonals (p11,p12,p21,p22) of Vf^-1 = [[p11,p12],[p21,p22]] (Vf: rcwa.py:1143-1147);
  *         phase [batch,n] = exp(i*omega*kz*thickness) (rcwa.py:1246).
  * Outputs S11, S21 [batch,n,n] (the layer's S22 == S11 and S12 == S21 identically), V [batch,n,n] (H_eigvec),
  *         optional Cplus, Cminus [batch,n,n]: Cf = [Cplus; Cminus], Cb = [Cminus; Cplus] (rcwa.py:1271-1274).
  * piv: int[3*batch*n], info: int[3*batch] (slot 0..B-1: P factorisation; B..3B-1: the two n x n inverses). */
 size_t trx_layer_smatrix_ws_bytes(int dtype, int N, int batch);
+/* H-field modes V = P^-1 W diag(kz) (rcwa.py:1248, 1264) of a layer with HOMOGENEOUS mu, from the rank-N structure
+ * P = mu J + [Kx; Ky] E^-1 [Ky, -Kx] (rcwa.py:1226-1228): one N x N factorisation of E - (Kx^2 + Ky^2)/mu and a 2N-column
+ * solve replace the LU of the 2N x 2N matrix P (0.29 n^3 instead of 1.33 n^3 complex MACs).  E [batch,N,N] permittivity
+ * convolution matrix (NOT its inverse), mu [batch], kx, ky [batch,N], W [batch,n,n], kz [batch,n]; V [batch,n,n] output.
+ * piv: int[batch*N], info: int[batch]; ws: trx_hmodes_ws_bytes. */
+size_t trx_hmodes_ws_bytes(int dtype, int N, int batch);
+int trx_hmodes(int dtype, const void* E, const void* mu, const void* kx, const void* ky, const void* W, const void* kz, int N, int batch,
+               void* V, int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
 int trx_layer_smatrix(int dtype, const void* P, const void* Q, const void* W, const void* kzfac, const void* vfinv,
                       const void* phase, int use_q, int N, int batch, void* S11, void* S21, void* V, void* Cplus,
                       void* Cminus, int* piv, int* info, void* ws, size_t ws_bytes, void* stream);

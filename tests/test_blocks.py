@@ -180,3 +180,31 @@ def test_redheffer_halfspace(backend, dtype, tol, side, want_xy):
         ref = _star(D, Sd) if side == 0 else _star(Sd, D)
         for k in range(4):
             assert np.abs(be.host(out[k])[b] - ref[k]).max() / np.abs(ref[k]).max() < tol, (side, want_xy, k)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-10), (np.complex64, 5e-4)])
+def test_hmodes_structured(backend, dtype, tol):
+    """trx_hmodes (rank-N structure of P) against the dense V = inv(P) W diag(kz) of torcwa/rcwa.py:1226-1228, 1248, 1264."""
+    be = get_backend(backend)
+    N, batch = 41, 2
+    n = 2 * N
+    E = (crand((batch, N, N), np.complex128) * 0.2 + 3.0 * np.eye(N)).astype(dtype)
+    mu = np.array([1.0 + 0.0j, 1.3 - 0.2j]).astype(dtype)
+    kx, ky = crand((batch, N), dtype), crand((batch, N), dtype)
+    W, kz = crand((batch, n, n), dtype), crand((batch, n), dtype)
+    V = be.empty((batch, n, n), dtype)
+    piv, info = be.empty((batch, N), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+    nws = be.lib.hmodes_ws_bytes(dtcode(dtype), N, batch)
+    ws = be.empty((nws,), np.uint8)
+    dE, dmu, dkx, dky, dW, dkz = [be.dev(x) for x in (E, mu, kx, ky, W, kz)]          # keep the device buffers alive across the call
+    rc = be.lib.hmodes(dtcode(dtype), be.ptr(dE), be.ptr(dmu), be.ptr(dkx), be.ptr(dky), be.ptr(dW), be.ptr(dkz), N, batch, be.ptr(V),
+                       be.ptr(piv), be.ptr(info), be.ptr(ws), nws, be.stream)
+    assert rc == 0 and (be.host(info) == 0).all()
+    for b in range(batch):
+        Kx, Ky = np.diag(kx[b].astype(np.complex128)), np.diag(ky[b].astype(np.complex128))
+        M = mu[b].astype(np.complex128) * np.eye(N)
+        Z = np.zeros((N, N))
+        P = np.block([[Z, M], [-M, Z]]) + np.vstack((Kx, Ky)) @ np.linalg.inv(E[b].astype(np.complex128)) @ np.hstack((Ky, -Kx))
+        ref = np.linalg.solve(P, W[b].astype(np.complex128) * kz[b].astype(np.complex128)[None, :])
+        assert np.abs(be.host(V)[b] - ref).max() / np.abs(ref).max() < tol

@@ -29,6 +29,8 @@ _SIGS = {
     "trx_layer_smatrix_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_layer_smatrix": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "trx_hmodes_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_hmodes": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_redheffer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_redheffer": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_redheffer_halfspace_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

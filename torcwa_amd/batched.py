@@ -237,6 +237,7 @@ class BatchedRCWA:
         self.Q.append(Q)
         self.kz_norm.append(kz)
         self.E_eigvec.append(W)
+        self._mu_scalar = mu_s if mu_h else None       # homogeneous mu: V = P^-1 W Kz from the rank-N structure of P (trx_hmodes)
         if diff:
             self._solve_layer_smatrix_diff()
         else:
@@ -305,7 +306,11 @@ class BatchedRCWA:
         phase = torch.exp(1j * (self.omega * d)[:, None] * kz)                          # rcwa.py:1246
         vfinv = torch.stack(self._Vfinv.d, dim=0).to(self._cdtype).contiguous()         # [4,B,N]
         if not self.avoid_Pinv_instability:
-            S11, S21, V, cp, cm = eng.layer_smatrix(P, None, W, kz, vfinv, phase, use_q=False, want_c=self.keep_coupling)
+            if self._mu_scalar is not None:                                             # rcwa.py:1264, structured (include/trx.h: trx_hmodes)
+                Vh = eng.hmodes(self.eps_conv[-1], self._mu_scalar, self.Kx_norm_dn, self.Ky_norm_dn, W, kz)
+                S11, S21, V, cp, cm = eng.layer_smatrix(None, None, W, kz, vfinv, phase, want_c=self.keep_coupling, V=Vh)
+            else:
+                S11, S21, V, cp, cm = eng.layer_smatrix(P, None, W, kz, vfinv, phase, use_q=False, want_c=self.keep_coupling)
         else:                                                                           # rcwa.py:1249-1262
             n = self.n
             I = torch.eye(n, dtype=self._cdtype, device=self._device)

@@ -153,6 +153,72 @@ int build_pq_t(hipStream_t s, const void* E, const void* Ei, const void* M, cons
     return TRX_OK;
 }
 
+// ---- V = P^-1 (W Kz) through the rank-N structure of P (homogeneous mu) -------------------------------------------------
+// P = mu J + [Kx; Ky] E^-1 [Ky, -Kx],  J = [[0, I], [-I, 0]]   (rcwa.py:1226-1228 with a scalar mu).  Woodbury:
+//   P^-1 B = C - (1/mu) [-Ky Y; Kx Y],   C = (1/mu) [-B2; B1],   (E - (Kx^2 + Ky^2)/mu) Y = Ky C1 - Kx C2
+// i.e. one N x N factorisation and one N x 2N-column solve (n^3/24 + n^3/4 complex MACs) instead of the LU of the 2N x 2N
+// matrix P and a 2N-column solve (n^3/3 + n^3).  E (not E^-1) is the matrix that gets factorised.
+template <class T>
+__global__ __launch_bounds__(256) void hm_inner_kernel(const cx<T>* __restrict__ E, const cx<T>* __restrict__ mu, const cx<T>* __restrict__ kx,
+                                                       const cx<T>* __restrict__ ky, int N, cx<T>* __restrict__ Mi) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const long o = ((long)b * N + i) * N + j;
+    cx<T> v = E[o];
+    if (i == j) {
+        const cx<T> x = kx[(long)b * N + i], y = ky[(long)b * N + i];
+        v -= cdiv(x * x + y * y, mu[b]);
+    }
+    Mi[o] = v;
+}
+// D[i, j] = (-ky_i B2[i,j] - kx_i B1[i,j]) / mu,   B = W Kz  (column j scaled by kz_j)
+template <class T>
+__global__ __launch_bounds__(256) void hm_rhs_kernel(const cx<T>* __restrict__ W, const cx<T>* __restrict__ kz, const cx<T>* __restrict__ mu,
+                                                     const cx<T>* __restrict__ kx, const cx<T>* __restrict__ ky, int N, cx<T>* __restrict__ D) {
+    const int b = blockIdx.z, i = blockIdx.y, n = 2 * N;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const cx<T>* Wb = W + (long)b * n * n;
+    const cx<T> k = kz[(long)b * n + j];
+    const cx<T> b1 = Wb[(long)i * n + j] * k, b2 = Wb[(long)(i + N) * n + j] * k;
+    const cx<T> x = kx[(long)b * N + i], y = ky[(long)b * N + i];
+    D[((long)b * N + i) * n + j] = cdiv(-(y * b2) - x * b1, mu[b]);
+}
+// V_top = (-B2 + ky Y)/mu,  V_bot = (B1 - kx Y)/mu
+template <class T>
+__global__ __launch_bounds__(256) void hm_finish_kernel(const cx<T>* __restrict__ W, const cx<T>* __restrict__ kz, const cx<T>* __restrict__ mu,
+                                                        const cx<T>* __restrict__ kx, const cx<T>* __restrict__ ky, const cx<T>* __restrict__ Y, int N,
+                                                        cx<T>* __restrict__ V) {
+    const int b = blockIdx.z, i = blockIdx.y, n = 2 * N;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const cx<T>* Wb = W + (long)b * n * n;
+    cx<T>* Vb = V + (long)b * n * n;
+    const cx<T> k = kz[(long)b * n + j];
+    const cx<T> b1 = Wb[(long)i * n + j] * k, b2 = Wb[(long)(i + N) * n + j] * k;
+    const cx<T> x = kx[(long)b * N + i], y = ky[(long)b * N + i];
+    const cx<T> yv = Y[((long)b * N + i) * n + j];
+    Vb[(long)i * n + j] = cdiv(y * yv - b2, mu[b]);
+    Vb[(long)(i + N) * n + j] = cdiv(b1 - x * yv, mu[b]);
+}
+template <class T>
+int hmodes_t(hipStream_t s, const cx<T>* E, const cx<T>* mu, const cx<T>* kx, const cx<T>* ky, const cx<T>* W, const cx<T>* kz, int N, int batch,
+             cx<T>* V, int* piv, int* info, cx<T>* ws) {
+    const int n = 2 * N;
+    const long NN = (long)N * N, Nn = (long)N * n;
+    cx<T>* Mi = ws;                         // [B,N,N]
+    cx<T>* D = ws + (long)batch * NN;       // [B,N,n]
+    const dim3 blk(256);
+    TRX_LAUNCH((hm_inner_kernel<T>), dim3(cdiv_i(N, 256), N, batch), blk, 0, s, E, mu, kx, ky, N, Mi);
+    TRX_LAUNCH((hm_rhs_kernel<T>), dim3(cdiv_i(n, 256), N, batch), blk, 0, s, W, kz, mu, kx, ky, N, D);
+    int rc = lu_factor<T>(s, Mi, N, NN, N, piv, batch, info); if (rc) return rc;
+    rc = lu_solve<T>(s, Mi, N, NN, N, piv, D, n, Nn, n, batch); if (rc) return rc;
+    TRX_LAUNCH((hm_finish_kernel<T>), dim3(cdiv_i(n, 256), N, batch), blk, 0, s, W, kz, mu, kx, ky, (const cx<T>*)D, N, V);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 template <class T>
 int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* W, const cx<T>* kz, const cx<T>* pv, const cx<T>* x, int use_q,
                     int N, int batch, cx<T>* S11, cx<T>* S21, cx<T>* V, cx<T>* cp, cx<T>* cm, int* piv, int* info, cx<T>* ws) {
@@ -164,7 +230,10 @@ int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* 
     cx<T>* G = ws + 2 * bn;      // [2B, n, n]: scratch (LU copy of P / inverse workspace / G1 | G2)
     cx<T>* Mx = ws + 4 * bn;     // [2B, n, n]: Mp | Mm
     int rc;
-    if (!use_q) {
+    if (use_q == 2) {
+        // V supplied by the caller (trx_hmodes)
+        if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    } else if (!use_q) {
         // V = P^-1 (W Kz)                                                       (rcwa.py:1248, 1264)
         if (hipMemcpyAsync(G, P, sizeof(cx<T>) * bn, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
         TRX_LAUNCH((scale_cols_kernel<T>), g, blk, 0, s, W, kz, n, V);
@@ -453,7 +522,7 @@ extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const 
                                  const void* phase, int use_q, int N, int batch, void* S11, void* S21, void* V, void* Cplus,
                                  void* Cminus, int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
     if (!W || !kzfac || !vfinv || !phase || !S11 || !S21 || !V || !piv || !info || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
-    if ((use_q && !Q) || (!use_q && !P)) return TRX_ERR_ARG;
+    if (use_q < 0 || use_q > 2 || (use_q == 1 && !Q) || (use_q == 0 && !P)) return TRX_ERR_ARG;
     if ((Cplus == nullptr) != (Cminus == nullptr)) return TRX_ERR_ARG;
     if (ws_bytes < trx_layer_smatrix_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
     hipStream_t s = trx::api_stream(stream);
@@ -465,6 +534,24 @@ extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const 
         return layer_smatrix_t<double>(s, (const cx<double>*)P, (const cx<double>*)Q, (const cx<double>*)W, (const cx<double>*)kzfac, (const cx<double>*)vfinv,
                                        (const cx<double>*)phase, use_q, N, batch, (cx<double>*)S11, (cx<double>*)S21, (cx<double>*)V, (cx<double>*)Cplus,
                                        (cx<double>*)Cminus, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}
+
+extern "C" size_t trx_hmodes_ws_bytes(int dtype, int N, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * 3 * (size_t)batch * N * N;
+}
+
+extern "C" int trx_hmodes(int dtype, const void* E, const void* mu, const void* kx, const void* ky, const void* W, const void* kz, int N, int batch,
+                          void* V, int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
+    if (!E || !mu || !kx || !ky || !W || !kz || !V || !piv || !info || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
+    if (ws_bytes < trx_hmodes_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = trx::api_stream(stream);
+    if (dtype == TRX_C64)
+        return hmodes_t<float>(s, (const cx<float>*)E, (const cx<float>*)mu, (const cx<float>*)kx, (const cx<float>*)ky, (const cx<float>*)W,
+                               (const cx<float>*)kz, N, batch, (cx<float>*)V, piv, info, (cx<float>*)ws);
+    if (dtype == TRX_C128)
+        return hmodes_t<double>(s, (const cx<double>*)E, (const cx<double>*)mu, (const cx<double>*)kx, (const cx<double>*)ky, (const cx<double>*)W,
+                                (const cx<double>*)kz, N, batch, (cx<double>*)V, piv, info, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
 }
 

@@ -146,13 +146,33 @@ class Engine:
                                          self._c(kx).data_ptr(), self._c(ky).data_ptr(), N, B, P.data_ptr(), Q.data_ptr(), self.stream))
         return P, Q
 
-    def layer_smatrix(self, P, Q, W, kzfac, vfinv, phase, *, use_q=False, want_c=True):
-        """Layer S-matrix (torcwa/rcwa.py:1244-1281).  vfinv: [4,B,N]; returns S11, S21, V, Cplus, Cminus."""
+    def hmodes(self, E, mu, kx, ky, W, kz):
+        """V = P^-1 W diag(kz) for homogeneous mu [B] via the rank-N structure of P (include/trx.h: trx_hmodes)."""
+        B, n, _ = W.shape
+        N = n // 2
+        dt = W.dtype
+        V = torch.empty((B, n, n), dtype=dt, device=self.device)
+        piv, info = self._ints(B * N), self._ints(B)
+        nws = self.lib.hmodes_ws_bytes(_CODE[dt], N, B)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.hmodes(_CODE[dt], self._c(E).data_ptr(), self._c(mu.to(dt)).data_ptr(), self._c(kx).data_ptr(), self._c(ky).data_ptr(),
+                                       self._c(W).data_ptr(), self._c(kz).data_ptr(), N, B, V.data_ptr(), piv.data_ptr(), info.data_ptr(),
+                                       ws.data_ptr(), nws, self.stream))
+        self._info(info, "hmodes")
+        return V
+
+    def layer_smatrix(self, P, Q, W, kzfac, vfinv, phase, *, use_q=False, want_c=True, V=None):
+        """Layer S-matrix (torcwa/rcwa.py:1244-1281).  vfinv: [4,B,N]; returns S11, S21, V, Cplus, Cminus.
+        V given (from hmodes): the H-field modes are taken as input (use_q = 2 of the C ABI)."""
         B, n, _ = W.shape
         N = n // 2
         dt = W.dtype
         S11 = torch.empty((B, n, n), dtype=dt, device=self.device)
-        S21, V = torch.empty_like(S11), torch.empty_like(S11)
+        S21 = torch.empty_like(S11)
+        if V is not None:
+            V, use_q = self._c(V), 2
+        else:
+            V = torch.empty_like(S11)
         cp = torch.empty_like(S11) if want_c else None
         cm = torch.empty_like(S11) if want_c else None
         piv, info = self._ints(3 * B * n), self._ints(3 * B)
