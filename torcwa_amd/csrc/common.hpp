@@ -135,7 +135,7 @@ struct GemmDesc {            // optional per-batch override (device array), used
 template <class T>
 int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
          const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch,
-         const GemmDesc* desc = nullptr);
+         const GemmDesc* desc = nullptr, int b_upper = 0);     // b_upper: op(B) is upper triangular (k == rows of op(B) indexed like its columns)
 
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);

@@ -103,12 +103,12 @@ int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>
         const int i1 = i0 + nbi;
         if (i1 < n) {
             int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nbi, n - i1, n - i1, one, B.A + (long)i0 * n + i1, n, nn, B.X + (long)i1 * n + i1, n, nn,
-                             zero, B.X + (long)i0 * n + i1, n, nn, batch);
+                             zero, B.X + (long)i0 * n + i1, n, nn, batch, nullptr, 1);     // X[i1:, i1:] is upper triangular
             if (rc) return rc;
         }
         TRX_LAUNCH((trevc_block_kernel<T>), dim3(cdiv_i(n - i0, 256), batch), dim3(256), 0, s, (const cx<T>*)B.A, B.X, n, i0, nbi, smlnum);
     }
-    int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, B.Z, n, nn, B.X, n, nn, zero, V, n, nn, batch);
+    int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, B.Z, n, nn, B.X, n, nn, zero, V, n, nn, batch, nullptr, 1);    // X upper triangular: half the K range
     if (rc) return rc;
     TRX_LAUNCH((colnorm_scale_kernel<T>), dim3(cdiv_i(n, 64), batch), dim3(256), 0, s, V, n);
     TRX_CHECK_LAUNCH();

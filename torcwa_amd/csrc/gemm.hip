@@ -21,7 +21,7 @@ constexpr int PLANE = 1280;      // max(64*LDK, 16*LDM)
 template <class T, int OPA, int OPB>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
-                                                        int ldc, long sC, const GemmDesc* __restrict__ desc) {
+                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
     __shared__ T Ar[PLANE];
     __shared__ T Ai[PLANE];
     __shared__ T Br[PLANE];
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     }
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= m || n0 >= n) return;
+    if (b_upper && n0 + BN < k) k = n0 + BN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
     const int t = threadIdx.x;
     constexpr bool A_KC = (OPA == TRX_OP_N);     // A's k index is contiguous in global memory
     constexpr bool B_KC = (OPB != TRX_OP_N);     // B's k index is contiguous in global memory
@@ -128,11 +129,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
 
 template <class T, int OPA>
 int launch_b(hipStream_t s, int opB, dim3 grid, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
-             const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc) {
+             const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
     switch (opB) {
-        case TRX_OP_N: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
-        case TRX_OP_T: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
-        case TRX_OP_C: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc); break;
+        case TRX_OP_N: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
+        case TRX_OP_T: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
+        case TRX_OP_C: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
         default: return TRX_ERR_ARG;
     }
     TRX_CHECK_LAUNCH();
@@ -142,24 +143,24 @@ int launch_b(hipStream_t s, int opB, dim3 grid, int m, int n, int k, cx<T> alpha
 
 template <class T>
 int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
-         const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc) {
+         const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc, int b_upper) {
     if (m <= 0 || n <= 0 || batch <= 0) return TRX_OK;
     if (k <= 0 && !desc) return TRX_ERR_ARG;          // callers never pass an empty inner dimension
     dim3 grid(cdiv_i(n, BN), cdiv_i(m, BM), batch);
     // algorithmic work of this launch: 8 real flops per complex MAC; bytes = A + B read once, C written (+read if beta)
-    const double macs = (double)m * n * k * batch;
+    const double macs = (double)m * n * k * batch * (b_upper ? 0.5 : 1.0);
     const double el = (double)sizeof(cx<T>) * batch;
     ProfScope prof((opA == TRX_OP_N && opB == TRX_OP_N) ? PROF_GEMM_NN : PROF_GEMM_OTHER, s, desc ? 0.0 : 8.0 * macs,
                    desc ? 0.0 : el * ((double)m * k + (double)k * n + (double)m * n * ((beta.x != T(0) || beta.y != T(0)) ? 2 : 1)));
     switch (opA) {
-        case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc);
-        case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc);
-        case TRX_OP_C: return launch_b<T, TRX_OP_C>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc);
+        case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        case TRX_OP_C: return launch_b<T, TRX_OP_C>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
         default: return TRX_ERR_ARG;
     }
 }
 
-template int gemm<float>(hipStream_t, int, int, int, int, int, cx<float>, const cx<float>*, int, long, const cx<float>*, int, long, cx<float>, cx<float>*, int, long, int, const GemmDesc*);
-template int gemm<double>(hipStream_t, int, int, int, int, int, cx<double>, const cx<double>*, int, long, const cx<double>*, int, long, cx<double>, cx<double>*, int, long, int, const GemmDesc*);
+template int gemm<float>(hipStream_t, int, int, int, int, int, cx<float>, const cx<float>*, int, long, const cx<float>*, int, long, cx<float>, cx<float>*, int, long, int, const GemmDesc*, int);
+template int gemm<double>(hipStream_t, int, int, int, int, int, cx<double>, const cx<double>*, int, long, const cx<double>*, int, long, cx<double>, cx<double>*, int, long, int, const GemmDesc*, int);
 
 }  // namespace trx
