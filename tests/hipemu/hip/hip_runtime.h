@@ -259,7 +259,9 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
     return ::hipemu::wave_read<T>(s);
 }
 inline void __builtin_amdgcn_wave_barrier() { ::hipemu::wave_post<int>(0); }
-inline void __builtin_amdgcn_sched_barrier(int) {}      // compiler scheduling fence: nothing to emulate
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline long long clock64() { return 0; }               // cycle counter: only used by optional debug timers
+inline long long wall_clock64() { return 0; }      // compiler scheduling fence: nothing to emulate
 inline unsigned long long __ballot(int pred) {
     ::hipemu::wave_post<int>(pred ? 1 : 2);          // 2 = participated, false; 0 = stale/not participating
     unsigned long long m = 0;

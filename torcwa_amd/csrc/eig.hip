@@ -22,7 +22,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U
     tot += al256(e * B * EigPlan::QNS);                               // shifts
     tot += al256(sizeof(QrState) * B);
-    tot += al256(sizeof(int) * 64);
+    tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
     return tot;
 }
 
@@ -46,7 +46,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QNS);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
-    Bf.summary = (int*)take(sizeof(int) * 64);   // up to 8 iteration groups x 8 ints
+    Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
 }
 
 namespace {
