@@ -19,9 +19,11 @@ def crand(shape, dtype):
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 2e-5)])
 @pytest.mark.parametrize("opA,opB", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (2, 2)])
-def test_gemm(backend, dtype, tol, opA, opB):
+@pytest.mark.parametrize("m,n,k", [(70, 67, 37), (70, 20, 37), (20, 150, 37), (32, 129, 64), (100, 32, 16)])
+def test_gemm(backend, dtype, tol, opA, opB, m, n, k):
+    """(70,67,37): general 64x64 tile with ragged edges; n <= 32: the 64x32 tile; m <= 32: the 32x128 tile."""
     be = get_backend(backend)
-    m, n, k, batch = 70, 67, 37, 2
+    batch = 2
     A = crand((batch, m, k) if opA == 0 else (batch, k, m), dtype)
     B = crand((batch, k, n) if opB == 0 else (batch, n, k), dtype)
     C0 = crand((batch, m, n), dtype)

@@ -2,30 +2,39 @@
 // Replaces the torch.matmul call sites of the reference hot path (torcwa/rcwa.py:1161-1164, 1226-1232,
 // 1236, 1260-1281, 1287-1304) and serves every block update of the LU and eigensolver kernels.
 //
-// Kernel: 64x64 block tile, BK = 16, 256 threads = 4 waves, wave w owns rows [16w,16w+16) x 64 columns
-// (4 MFMA tiles, complex accumulators = 32 acc registers).  Operands are staged through LDS as split re/im
-// planes whose in-LDS orientation follows the operand's global orientation, so that both the global->LDS copy
-// and the MFMA fragment reads are contiguous / bank-conflict free (see mfma.hpp); the next K-slab is prefetched
-// into registers while the current one is multiplied.
+// Kernel: BK = 16, 256 threads = 4 waves arranged WR x (4/WR); a wave owns 16 rows x 16*NT columns (NT MFMA tiles, complex
+// accumulators).  Three block tiles cover the shapes of the hot path:
+//   <WR=4,NT=4>  64 x 64    the general case
+//   <WR=4,NT=2>  64 x 32    outputs at most 32 columns wide (panel products Z V, A V of the Hessenberg reduction)
+//   <WR=2,NT=4>  32 x 128   outputs at most 32 rows high   (V^H A of the Hessenberg reduction, the back-substitution blocks)
+// so that a 32-wide panel no longer pays for a half-empty 64-wide tile.  Operands are staged through LDS as split re/im
+// planes whose in-LDS orientation follows the operand's global orientation, so that both the global->LDS copy and the MFMA
+// fragment reads are contiguous / bank-conflict free (see mfma.hpp); the next K-slab is prefetched into registers while
+// the current one is multiplied.
 #include "mfma.hpp"
 #include "prof.hpp"
 
 namespace trx {
 
 namespace {
-constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int BK = 16;
 constexpr int LDK = BK + 2;      // k-contiguous plane: element (major, k) at [major*LDK + k]
-constexpr int LDM = 80;          // major-contiguous plane: element (major, k) at [k*LDM + major]
-constexpr int PLANE = 1280;      // max(64*LDK, 16*LDM)
+// major-contiguous plane: element (major, k) at [k*ldm + major], ldm = 16 (mod 32) and >= the tile extent
+constexpr int ldm_of(int extent) { return extent <= 64 ? 80 : 144; }
+constexpr int plane_of(int extent) { return (extent * LDK > BK * ldm_of(extent)) ? extent * LDK : BK * ldm_of(extent); }
 
-template <class T, int OPA, int OPB>
+template <class T, int OPA, int OPB, int WR, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
                                                         int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
-    __shared__ T Ar[PLANE];
-    __shared__ T Ai[PLANE];
-    __shared__ T Br[PLANE];
-    __shared__ T Bi[PLANE];
+    constexpr int WC = 4 / WR;                   // waves along N
+    constexpr int BM = 16 * WR, BN = 16 * NT * WC;
+    constexpr int LDMA = ldm_of(BM), LDMB = ldm_of(BN);
+    constexpr int RA = BM / 16, RB = BN / 16;    // elements per thread and slab of the A / B tile
+    __shared__ T Ar[plane_of(BM)];
+    __shared__ T Ai[plane_of(BM)];
+    __shared__ T Br[plane_of(BN)];
+    __shared__ T Bi[plane_of(BN)];
     const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
@@ -41,52 +50,57 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     const int t = threadIdx.x;
     constexpr bool A_KC = (OPA == TRX_OP_N);     // A's k index is contiguous in global memory
     constexpr bool B_KC = (OPB != TRX_OP_N);     // B's k index is contiguous in global memory
-    constexpr int sAr = A_KC ? LDK : 1, sAk = A_KC ? 1 : LDM;
-    constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDM;
+    constexpr int sAr = A_KC ? LDK : 1, sAk = A_KC ? 1 : LDMA;
+    constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDMB;
 
-    cx<T> ra[4], rb[4];
+    cx<T> ra[RA], rb[RB];
     // Branch-free tile loads: out-of-range coordinates are clamped to a valid address and the value is zeroed by a
-    // select, so the 8 global_load_dwordx4 of a slab issue back-to-back instead of each sitting in its own exec branch.
+    // select, so the global_load_dwordx4 of a slab issue back-to-back instead of each sitting in its own exec branch.
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
-            {
-                const int row = A_KC ? (e >> 4) : (e & 63), kk = A_KC ? (e & 15) : (e >> 6);
-                const bool ok = (m0 + row < m) && (k0 + kk < k);
-                const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-                cx<T> v = (OPA == TRX_OP_N) ? A[(long)gr * lda + gk] : A[(long)gk * lda + gr];
-                if (OPA == TRX_OP_C) v.y = -v.y;
-                ra[r] = ok ? v : cx<T>(T(0), T(0));
-            }
-            {
-                const int col = B_KC ? (e >> 4) : (e & 63), kk = B_KC ? (e & 15) : (e >> 6);
-                const bool ok = (n0 + col < n) && (k0 + kk < k);
-                const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-                cx<T> v = (OPB == TRX_OP_N) ? B[(long)gk * ldb + gc] : B[(long)gc * ldb + gk];
-                if (OPB == TRX_OP_C) v.y = -v.y;
-                rb[r] = ok ? v : cx<T>(T(0), T(0));
-            }
+            const int row = A_KC ? (e >> 4) : (e % BM), kk = A_KC ? (e & 15) : (e / BM);
+            const bool ok = (m0 + row < m) && (k0 + kk < k);
+            const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
+            cx<T> v = (OPA == TRX_OP_N) ? A[(long)gr * lda + gk] : A[(long)gk * lda + gr];
+            if (OPA == TRX_OP_C) v.y = -v.y;
+            ra[r] = ok ? v : cx<T>(T(0), T(0));
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int e = t + 256 * r;
+            const int col = B_KC ? (e >> 4) : (e % BN), kk = B_KC ? (e & 15) : (e / BN);
+            const bool ok = (n0 + col < n) && (k0 + kk < k);
+            const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
+            cx<T> v = (OPB == TRX_OP_N) ? B[(long)gk * ldb + gc] : B[(long)gc * ldb + gk];
+            if (OPB == TRX_OP_C) v.y = -v.y;
+            rb[r] = ok ? v : cx<T>(T(0), T(0));
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
-            const int row = A_KC ? (e >> 4) : (e & 63), ka = A_KC ? (e & 15) : (e >> 6);
-            const int col = B_KC ? (e >> 4) : (e & 63), kb = B_KC ? (e & 15) : (e >> 6);
+            const int row = A_KC ? (e >> 4) : (e % BM), ka = A_KC ? (e & 15) : (e / BM);
             Ar[row * sAr + ka * sAk] = ra[r].x; Ai[row * sAr + ka * sAk] = ra[r].y;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int e = t + 256 * r;
+            const int col = B_KC ? (e >> 4) : (e % BN), kb = B_KC ? (e & 15) : (e / BN);
             Br[col * sBc + kb * sBk] = rb[r].x; Bi[col * sBc + kb * sBk] = rb[r].y;
         }
     };
 
-    typename Mfma<T>::acc_t accR[4], accI[4];
+    typename Mfma<T>::acc_t accR[NT], accI[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
 
     const int wave = t >> 6, lane = t & 63;
+    const int arow0 = 16 * (wave % WR), bcol0 = 16 * NT * (wave / WR);
     const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
     const int col_l = lane & 15;
     load_tiles(0);
@@ -94,31 +108,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         store_tiles();
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
-        cmma_tile_strided<T, 4>(Ar, Ai, sAr, sAk, 16 * wave, Br, Bi, sBk, sBc, 0, BK, accR, accI);
+        cmma_tile_strided<T, NT>(Ar, Ai, sAr, sAk, arow0, Br, Bi, sBk, sBc, bcol0, BK, accR, accI);
         __syncthreads();
     }
-    // C tile of this lane (beta != 0): all 16 loads are issued back to back with clamped addresses (the guards sit at the
+    // C tile of this lane (beta != 0): all loads are issued back to back with clamped addresses (the guards sit at the
     // store), so a rank-32/64 update pays the read latency of C once instead of once per element behind an exec branch.
-    cx<T> cv[4][4];
+    cx<T> cv[4][NT];
     if (has_beta) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 16 * wave + Mfma<T>::crow(lane, r);
+            const int row = m0 + arow0 + Mfma<T>::crow(lane, r);
             const int rc = row < m ? row : m - 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + 16 * j + col_l;
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + bcol0 + 16 * j + col_l;
                 cv[r][j] = C[(long)rc * ldc + (col < n ? col : n - 1)];
             }
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 16 * wave + Mfma<T>::crow(lane, r);
+        const int row = m0 + arow0 + Mfma<T>::crow(lane, r);
         if (row >= m) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + 16 * j + col_l;
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + bcol0 + 16 * j + col_l;
             if (col >= n) continue;
             cx<T> v = alpha * cx<T>(accR[j][r], accI[j][r]);
             if (has_beta) v += beta * cv[r][j];
@@ -127,13 +141,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     }
 }
 
+template <class T, int OPA, int OPB>
+void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
+                  const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
+    if (shape == 1)
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+    else if (shape == 2)
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+    else
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+}
+
 template <class T, int OPA>
-int launch_b(hipStream_t s, int opB, dim3 grid, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
+int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
              const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
     switch (opB) {
-        case TRX_OP_N: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
-        case TRX_OP_T: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
-        case TRX_OP_C: TRX_LAUNCH((gemm_mfma_kernel<T, OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
+        case TRX_OP_N: launch_shape<T, OPA, TRX_OP_N>(s, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
+        case TRX_OP_T: launch_shape<T, OPA, TRX_OP_T>(s, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
+        case TRX_OP_C: launch_shape<T, OPA, TRX_OP_C>(s, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper); break;
         default: return TRX_ERR_ARG;
     }
     TRX_CHECK_LAUNCH();
@@ -146,16 +171,18 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
          const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc, int b_upper) {
     if (m <= 0 || n <= 0 || batch <= 0) return TRX_OK;
     if (k <= 0 && !desc) return TRX_ERR_ARG;          // callers never pass an empty inner dimension
-    dim3 grid(cdiv_i(n, BN), cdiv_i(m, BM), batch);
+    // block-tile shape: 64x32 for narrow outputs, 32x128 for flat ones (per-batch descriptors keep the general tile: their
+    // sizes are only known on the device)
+    const int shape = desc ? 0 : (n <= 32 ? 1 : (m <= 32 ? 2 : 0));
     // algorithmic work of this launch: 8 real flops per complex MAC; bytes = A + B read once, C written (+read if beta)
     const double macs = (double)m * n * k * batch * (b_upper ? 0.5 : 1.0);
     const double el = (double)sizeof(cx<T>) * batch;
     ProfScope prof((opA == TRX_OP_N && opB == TRX_OP_N) ? PROF_GEMM_NN : PROF_GEMM_OTHER, s, desc ? 0.0 : 8.0 * macs,
                    desc ? 0.0 : el * ((double)m * k + (double)k * n + (double)m * n * ((beta.x != T(0) || beta.y != T(0)) ? 2 : 1)));
     switch (opA) {
-        case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
-        case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
-        case TRX_OP_C: return launch_b<T, TRX_OP_C>(s, opB, grid, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        case TRX_OP_C: return launch_b<T, TRX_OP_C>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
         default: return TRX_ERR_ARG;
     }
 }
