@@ -67,7 +67,7 @@ PEAK_TFLOPS = {"high": 78.6, "native": 157.3}
 PEAK_HBM_GBS = 8000.0
 
 
-def roofline(engine, precision, elapsed):
+def roofline(engine, precision, elapsed, batch_per_gpu=None):
     """Live figures from the HIP events libtrx recorded around its dominant kernels during the timed region."""
     import ctypes
     tags = []
@@ -102,7 +102,26 @@ def roofline(engine, precision, elapsed):
             tf = a["flops_all"] / (a["ms_timed"] * 1e-3 * a["launches"] / a["timed_launches"]) / 1e12
             roof["qr_slab_updates"] = {"kernel": a["kernel"], "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                                        "frac": tf / PEAK_TFLOPS[precision], "avg_launch_us": 1e3 * a["ms_timed"] / a["timed_launches"],
-                                       "note": "flops = 8 ww^2 (2n - ww) per matrix and window step, summed on the device over all launches"}
+                                       "note": "flops = 8 ww^2 (2n - ww) per matrix and window step, summed on the device over all launches; up to 4 iteration "
+                                               "groups run this kernel concurrently on their own streams, so the event-bracketed time of a launch includes "
+                                               "the share of the GPU the other groups take: this is the rate ONE group sees, the aggregate is up to 4x"}
+    # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot be
+    # collected from inside this process).  Only reported when the committed summary was taken at this batch size.
+    if roof is not None:
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
+        try:
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            if pmc.get("batch") == batch_per_gpu:
+                kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("gemm_mfma_kernel<double, 0, 0" if precision == "high" else "gemm_mfma_kernel<float, 0, 0")]
+                if kk:
+                    tot = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk)
+                    n_l = sum(v["launches"] for v in kk)
+                    roof["traffic"] = tot / n_l
+                    roof["traffic_note"] = ("HBM bytes per launch, average over the launches of this kernel in one step: 2*FETCH_SIZE + WRITE_SIZE from "
+                                            "profiles/r01_pmc_bench.json (separate --pmc passes of the same command)")
+        except (OSError, ValueError, KeyError):
+            pass
     return roof, times
 
 
@@ -195,7 +214,7 @@ def main():
                        "batch_per_gpu": args.batch, "chunk": chunk, "streams": args.streams, "precision": args.precision},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "numerical_failures": 0, "hbm": mem,
         }
-        res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed)
+        res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed, args.batch)
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads if args.cpu_threads > 0 else max(1, (os.cpu_count() or 2) // 2)
             from torcwa_amd.sweep import asih_eps_table
