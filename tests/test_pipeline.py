@@ -192,3 +192,38 @@ def test_stack_sweep_driver_matches_drop_in(backend):
         sim.solve_global_smatrix()
         ref = sim.S_parameters([[0, 0], [-1, 0]], polarization="yy").cpu().numpy()
         assert np.abs(got[b] - ref).max() < 1e-10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("stack", ["hp", "ph", "hh", "h_only", "hph"])
+def test_homogeneous_layers_block_diagonal_path(backend, stack):
+    """keep_coupling=False solves homogeneous layers in closed form (2x2-block-diagonal S-matrices, O(N)) and cascades them with
+    the half-space star product; the result must equal the dense path (keep_coupling=True), which follows rcwa.py:1206-1222
+    and 1244-1306 operation by operation.  h = homogeneous (complex eps, mu != 1), p = patterned."""
+    import torcwa_amd
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(5)
+    B, order, L = 2, [2, 1], [310., 270.]
+    grid = (1.0 + 4.0 * torch.rand(B, 14, 12, generator=gen, dtype=torch.float64)).to(eng.device)
+    freq = torch.tensor([1 / 500., 1 / 590.], dtype=torch.float64)
+    hom = [(60., 2.3 + 0.1j, 1.0), (35., 1.7, 1.2)]
+    res = []
+    for keep in (False, True):
+        sim = torcwa_amd.BatchedRCWA(freq, order, L, dtype=torch.complex128, engine=eng, keep_coupling=keep)
+        if stack != "h_only":
+            sim.add_input_layer(eps=2.1)
+            sim.add_output_layer(eps=1.4)
+        sim.set_incident_angle(torch.tensor([0.1, 0.3], dtype=torch.float64), 0.2)
+        ih = 0
+        for ch in stack.replace("_only", ""):
+            if ch == "h":
+                d, e, m = hom[ih % 2]
+                ih += 1
+                sim.add_layer(d, e, m)
+            else:
+                sim.add_layer(torch.tensor([80., 95.]), grid)
+        sim.solve_global_smatrix()
+        res.append([sim.S_parameters([[0, 0], [1, 0], [0, -1]], direction=dr, port=pt, polarization=pol).cpu().numpy()
+                    for dr, pt in (("f", "t"), ("f", "r"), ("b", "t"), ("b", "r")) for pol in ("xx", "yx", "ps")])
+    for a, b in zip(*res):
+        assert np.abs(a - b).max() < 1e-10

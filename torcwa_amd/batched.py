@@ -193,6 +193,9 @@ class BatchedRCWA:
             C = eng.convmat(g.contiguous(), self.order[0], self.order[1], cdt)          # rcwa.py:1183-1204
             return C, None, None
 
+        if eps_h and mu_h and not diff and not self.keep_coupling:
+            self._add_homogeneous_layer_bd(thickness, self._bvec(eps), self._bvec(mu))
+            return
         E, Einv, eps_s = conv(eps, eps_h)
         M, Minv, mu_s = conv(mu, mu_h)
         self.eps_conv.append(E)
@@ -242,6 +245,32 @@ class BatchedRCWA:
             self._solve_layer_smatrix_diff()
         else:
             self._solve_layer_smatrix()
+
+    def _add_homogeneous_layer_bd(self, thickness, eps_s, mu_s):
+        """Homogeneous layer without field bookkeeping (keep_coupling=False): every operator of rcwa.py:1206-1222 and 1244-1281
+        is 2x2-block-diagonal (W = I, V = P^-1 Kz = Q Kz^-1 in closed form), so the layer S-matrix is four [B,N] diagonals per
+        block and costs O(N) instead of the dense eigen/LU path; the cascade then uses the half-space star product.  The dense
+        per-layer attributes (P, Q, E_eigvec, H_eigvec, eps_conv, mu_conv) are not materialised for such a layer (None)."""
+        kxd, kyd = self.Kx_norm_dn, self.Ky_norm_dn
+        d = self._bvec(thickness, self._rdtype)
+        epsmu = (eps_s * mu_s)[:, None]
+        kz = torch.sqrt(epsmu - kxd ** 2 - kyd ** 2)
+        kz = torch.where(torch.imag(kz) < 0, torch.conj(kz), kz)                        # rcwa.py:1218
+        x = torch.exp(1j * (self.omega * d)[:, None] * kz)                              # rcwa.py:1246, [B,N] (same for both field components)
+        V = _halfspace_V(kxd, kyd, epsmu).scale(1 / mu_s[:, None])                      # Q Kz^-1 = P^-1 Kz
+        one, zero = torch.ones_like(kz), torch.zeros_like(kz)
+        I = BlockDiag2(one, zero, zero, one)
+        F = self._Vfinv @ V
+        A_, B_ = I + F, (I - F).scale(x)
+        Tip, Tim = (A_ + B_).inv(), (A_ - B_).inv()
+        cp, cm = Tip + Tim, Tip - Tim
+        self.layer_S11.append(cp.scale(x) + cm)                                         # rcwa.py:1276 with W = I
+        self.layer_S21.append(cp + cm.scale(x) - I)                                     # rcwa.py:1277
+        self.layer_N += 1
+        self.thickness.append(d)
+        self.kz_norm.append(torch.cat((kz, kz), dim=1))
+        for lst in (self.eps_conv, self.mu_conv, self.P, self.Q, self.E_eigvec, self.H_eigvec, self.Cplus, self.Cminus):
+            lst.append(None)
 
     @staticmethod
     def _pq_torch(E, Ei, M, Mi, kx, ky):
@@ -368,12 +397,36 @@ class BatchedRCWA:
                 Cn[1].append(eng.gemm(C[1][m], Y2.contiguous()))
         return Sn, Cn
 
+    @staticmethod
+    def _is_bd(S):
+        return isinstance(S[0], BlockDiag2)
+
+    @staticmethod
+    def _RS_bd_bd(Sm, Sn):
+        """Star product of two block-diagonal S-matrices (rcwa.py:1287-1296), O(N)."""
+        one, zero = torch.ones_like(Sm[0].d[0]), torch.zeros_like(Sm[0].d[0])
+        I = BlockDiag2(one, zero, zero, one)
+        t1 = (I - Sm[2] @ Sn[1]).inv()
+        t2 = (I - Sn[1] @ Sm[2]).inv()
+        return [Sn[0] @ t1 @ Sm[0], Sm[1] + Sm[3] @ t2 @ Sn[1] @ Sm[0], Sn[2] + Sn[0] @ t1 @ Sm[2] @ Sn[3], Sm[3] @ t2 @ Sn[3]]
+
+    def _star(self, Sm, Sn, Cm, Cn):
+        """Sm * Sn for any mix of dense ([B,n,n] tensors) and block-diagonal (BlockDiag2) operands."""
+        bm, bn = self._is_bd(Sm), self._is_bd(Sn)
+        if bm and bn:
+            return self._RS_bd_bd(Sm, Sn), [[], []]
+        if bm:
+            return self._RS_halfspace(0, Sm, Sn, Cn)
+        if bn:
+            return self._RS_halfspace(1, Sn, Sm, Cm)
+        return self._RS_prod(Sm, Sn, Cm, Cn)
+
     def _layer_S(self, i):
         # the layer S-matrix is symmetric under port exchange: S22 = S11, S12 = S21 (SURVEY.md section 7.2)
         return [self.layer_S11[i], self.layer_S21[i], self.layer_S21[i], self.layer_S11[i]]
 
     def _layer_C(self, i):
-        if not self.keep_coupling:
+        if not self.keep_coupling or self.Cplus[i] is None:
             return [[], []]
         return [[torch.cat((self.Cplus[i], self.Cminus[i]), dim=1)], [torch.cat((self.Cminus[i], self.Cplus[i]), dim=1)]]
 
@@ -390,11 +443,13 @@ class BatchedRCWA:
             C = [[], []]
             self._zero_layer_S = not (self.has_in or self.has_out)     # reference stores 1-D zeros (rcwa.py:187-188)
         for i in range(1, self.layer_N):
-            S, C = self._RS_prod(S, self._layer_S(i), C, self._layer_C(i))
+            S, C = self._star(S, self._layer_S(i), C, self._layer_C(i))
         if self.has_in:                                                                 # rcwa.py:198-202
-            S, C = self._RS_halfspace(0, self._Sin, S, C)
+            S, C = self._star(self._Sin, S, [[], []], C)
         if self.has_out:                                                                # rcwa.py:204-208
-            S, C = self._RS_halfspace(1, self._Sout, S, C)
+            S, C = self._star(S, self._Sout, C, [[], []])
+        if self._is_bd(S):                                                              # only homogeneous media: densify for the read-out
+            S = [blk.dense().to(self._cdtype) for blk in S]
         self.S = S
         self.C = C
 
