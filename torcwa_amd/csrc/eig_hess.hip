@@ -165,15 +165,25 @@ __global__ __launch_bounds__(256) void hess_gemv_kernel(const cx<T>* __restrict_
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rbeg = r0 + blockIdx.x * rows_per_block;
-    for (int rr = wid; rr < rows_per_block; rr += nw) {
-        const int r = rbeg + rr;
-        if (r >= n) break;
-        const cx<T>* row = A + (long)r * n + j + 1;
-        cx<T> acc(T(0), T(0));
-        for (int i = lane; i < len; i += 64) cfma(acc, row[i], v[i]);
-        acc.x = wave_sum(acc.x);
-        acc.y = wave_sum(acc.y);
-        if (lane == 0) Y[(long)r * HNB + c] = acc;
+    // two rows per wave and pass: the v element read from LDS serves both, and twice as many row loads are in flight
+    for (int rr = 2 * wid; rr < rows_per_block; rr += 2 * nw) {
+        const int ra = rbeg + rr;
+        if (ra >= n) break;
+        const bool two = (rr + 1 < rows_per_block) && (ra + 1 < n);
+        const cx<T>* rowa = A + (long)ra * n + j + 1;
+        const cx<T>* rowb = two ? rowa + n : rowa;
+        cx<T> acca(T(0), T(0)), accb(T(0), T(0));
+        for (int i = lane; i < len; i += 64) {
+            const cx<T> vi = v[i];
+            cfma(acca, rowa[i], vi);
+            cfma(accb, rowb[i], vi);
+        }
+        acca.x = wave_sum(acca.x); acca.y = wave_sum(acca.y);
+        accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y);
+        if (lane == 0) {
+            Y[(long)ra * HNB + c] = acca;
+            if (two) Y[(long)(ra + 1) * HNB + c] = accb;
+        }
     }
 }
 
@@ -222,7 +232,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
             TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(512), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau);
             if (c < ib) {
                 const int j = p0 + c;
-                const int rpb = 32;
+                const int rpb = 64;
                 // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
                 ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
                 TRX_LAUNCH((hess_gemv_kernel<T>), dim3(cdiv_i(nr, rpb), batch), dim3(256), sizeof(cx<T>) * (size_t)(n - j - 1), s,
