@@ -70,6 +70,15 @@ size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
 
+/* Adjoint of the eigendecomposition: torcwa/torch_eig.py:19-44 (`Eig.backward`, the Lorentzian-broadened formula)
+ *   gA = (V^H)^-1 (diag(gw) + conj(F) o (V^H gV)) V^H,   F_ij = conj(w_j - w_i) / (|w_j - w_i|^2 + broadening), F_ii = 0.
+ * w [batch,n], V [batch,n,n] as returned by trx_eig; gw [batch,n], gV [batch,n,n] incoming gradients; gA [batch,n,n] output.
+ * broadening: `Eig.broadening_parameter` (1e-10 by default); pass the smallest positive number of the dtype to reproduce the
+ * reference's un-broadened branch (torch_eig.py:27-31).  piv: int[batch*n], info: int[batch] (LU of V^H). */
+size_t trx_eig_backward_ws_bytes(int dtype, int n, int batch);
+int trx_eig_backward(int dtype, const void* w, const void* V, const void* gw, const void* gV, double broadening, int n, int batch,
+                     void* gA, int* piv, int* info, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- layer eigenproblem assembly: torcwa/rcwa.py:1224-1232 (`_eigen_decomposition`, P and Q) -------------------
  * P = [[Kx Ei Ky, M - Kx Ei Kx],[Ky Ei Ky - M, -Ky Ei Kx]],  Q = [[-Kx Mi Ky, Kx Mi Kx - E],[E - Ky Mi Ky, Ky Mi Kx]]
  * E, Einv, Mu, Muinv: [batch,N,N] (Einv = inverse of the permittivity convolution matrix, etc.);

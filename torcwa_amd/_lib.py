@@ -6,7 +6,7 @@ infrastructure and never loaded from here.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrx.so")
@@ -29,6 +29,8 @@ _SIGS = {
     "trx_layer_smatrix_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_layer_smatrix": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "trx_eig_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_eig_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_hmodes_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_hmodes": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_redheffer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

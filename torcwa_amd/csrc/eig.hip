@@ -72,12 +72,82 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
 }
 }  // namespace
 
+// ---- adjoint of the eigendecomposition: torcwa/torch_eig.py:19-44 (the reference's Lorentzian-broadened formula) ------------
+//   s_ij = w_j - w_i,  F = conj(s) / (|s|^2 + eps), F_ii = 0
+//   gA = (V^H)^-1 (diag(gw) + conj(F) o (V^H gV)) V^H
+// inner <- diag(gw) + conj(F) o M   (in place on M = V^H gV)
+template <class T>
+__global__ __launch_bounds__(256) void eigbwd_inner_kernel(const cx<T>* __restrict__ w, const cx<T>* __restrict__ gw, cx<T>* __restrict__ M, int n, T eps) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const cx<T>* wb = w + (long)b * n;
+    cx<T>* p = M + ((long)b * n + i) * n + j;
+    if (i == j) { *p = gw[(long)b * n + i]; return; }
+    const cx<T> sij = wb[j] - wb[i];
+    const T den = norm2(sij) + eps;
+    *p = cx<T>(sij.x / den, sij.y / den) * (*p);          // conj(F_ij) = s_ij / (|s_ij|^2 + eps)
+}
+// out[b] = conj(in[b])^T
+template <class T>
+__global__ __launch_bounds__(256) void conj_transpose_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, int n) {
+    __shared__ cx<T> tile[32][33];
+    in += (long)blockIdx.z * n * n;
+    out += (long)blockIdx.z * n * n;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < n && c < n) tile[i][threadIdx.x] = conj(in[(long)r * n + c]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = c0 + i, c = r0 + threadIdx.x;
+        if (r < n && c < n) out[(long)r * n + c] = tile[threadIdx.x][i];
+    }
+}
+template <class T>
+int eig_backward_t(hipStream_t s, const cx<T>* w, const cx<T>* V, const cx<T>* gw, const cx<T>* gV, double eps, int n, int batch, cx<T>* gA,
+                   int* piv, int* info, cx<T>* ws) {
+    const long nn = (long)n * n;
+    const cx<T> one(T(1), T(0)), zero(T(0), T(0));
+    cx<T>* M = ws;                             // [B,n,n]  V^H gV -> inner
+    cx<T>* XH = ws + (long)batch * nn;         // [B,n,n]  V^H (factored in place)
+    int rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, n, n, n, one, V, n, nn, gV, n, nn, zero, M, n, nn, batch); if (rc) return rc;
+    TRX_LAUNCH((eigbwd_inner_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, w, gw, M, n, (T)eps);
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, n, n, n, one, M, n, nn, V, n, nn, zero, gA, n, nn, batch); if (rc) return rc;      // inner V^H
+    TRX_LAUNCH((conj_transpose_kernel<T>), dim3(cdiv_i(n, 32), cdiv_i(n, 32), batch), dim3(32, 8), 0, s, V, XH, n);
+    rc = lu_factor<T>(s, XH, n, nn, n, piv, batch, info); if (rc) return rc;
+    rc = lu_solve<T>(s, XH, n, nn, n, piv, gA, n, nn, n, batch); if (rc) return rc;
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 template size_t eig_ws_bytes_t<float>(int, int);
 template size_t eig_ws_bytes_t<double>(int, int);
 template void eig_carve<float>(EigBuffers<float>&, void*, void*, int, int);
 template void eig_carve<double>(EigBuffers<double>&, void*, void*, int, int);
 
 }  // namespace trx
+
+using trx::cx;
+
+extern "C" size_t trx_eig_backward_ws_bytes(int dtype, int n, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * 2 * (size_t)batch * n * n;
+}
+
+extern "C" int trx_eig_backward(int dtype, const void* w, const void* V, const void* gw, const void* gV, double broadening, int n, int batch,
+                                void* gA, int* piv, int* info, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !V || !gw || !gV || !gA || !piv || !info || !ws || n <= 0 || batch <= 0 || !(broadening >= 0.0)) return TRX_ERR_ARG;
+    if (ws_bytes < trx_eig_backward_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = trx::api_stream(stream);
+    if (dtype == TRX_C64)
+        return trx::eig_backward_t<float>(s, (const cx<float>*)w, (const cx<float>*)V, (const cx<float>*)gw, (const cx<float>*)gV, broadening, n, batch,
+                                     (cx<float>*)gA, piv, info, (cx<float>*)ws);
+    if (dtype == TRX_C128)
+        return trx::eig_backward_t<double>(s, (const cx<double>*)w, (const cx<double>*)V, (const cx<double>*)gw, (const cx<double>*)gV, broadening, n, batch,
+                                      (cx<double>*)gA, piv, info, (cx<double>*)ws);
+    return TRX_ERR_DTYPE;
+}
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {
     if (n <= 0 || batch <= 0) return 0;

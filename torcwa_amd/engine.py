@@ -136,6 +136,20 @@ class Engine:
         self._info(info, "eig")
         return w, V
 
+    def eig_backward(self, w, V, gw, gV, broadening):
+        """gA of the reference's broadened eig adjoint (torcwa/torch_eig.py:19-44) in one library call."""
+        B, n, _ = V.shape
+        dt = V.dtype
+        gA = torch.empty((B, n, n), dtype=dt, device=self.device)
+        piv, info = self._ints(B * n), self._ints(B)
+        nws = self.lib.eig_backward_ws_bytes(_CODE[dt], n, B)
+        ws = self._ws(nws)
+        self.lib.check(self.lib.eig_backward(_CODE[dt], self._c(w).data_ptr(), self._c(V).data_ptr(), self._c(gw.to(dt)).data_ptr(),
+                                             self._c(gV.to(dt)).data_ptr(), float(broadening), n, B, gA.data_ptr(), piv.data_ptr(), info.data_ptr(),
+                                             ws.data_ptr(), nws, self.stream))
+        self._info(info, "eig_backward")
+        return gA
+
     # -- a6 / a8 / a9 ----------------------------------------------------------------------------------
     def build_pq(self, E, Einv, M, Minv, kx, ky):
         B, N, _ = E.shape

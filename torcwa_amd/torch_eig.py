@@ -1,8 +1,8 @@
 """`Eig`: the reference's single-op plugin seam (torcwa/torch_eig.py:8-44), served by libtrx.
 
 forward  : trx_eig (batched HIP eigensolver) instead of torch.linalg.eig            (torch_eig.py:12-17)
-backward : torcwa's own broadened adjoint, F = conj(s)/(|s|^2 + eps), with the dense products and the
-           (V^H)^-1 solve done by libtrx GEMM / LU kernels                           (torch_eig.py:20-44)
+backward : torcwa's own broadened adjoint, F = conj(s)/(|s|^2 + eps): trx_eig_backward (two GEMMs, one fused
+           elementwise kernel, one LU solve with V^H)                                (torch_eig.py:20-44)
 Accepts [n,n] (like the reference) or batched [B,n,n] input.
 """
 import torch
@@ -38,19 +38,13 @@ class Eig(torch.autograd.Function):
         gw = grad_eigval if ctx.batched else grad_eigval[None]
         gV = grad_eigvec if ctx.batched else grad_eigvec[None]
         gw, gV = gw.to(w.dtype), gV.to(V.dtype)
-        s = w.unsqueeze(-2) - w.unsqueeze(-1)                       # s_ij = w_j - w_i
+        # F = conj(s)/(|s|^2 + eps), s_ij = w_j - w_i; eps = broadening, or the smallest positive number of the dtype when the
+        # broadening is switched off (torch_eig.py:27-31); the whole adjoint is one libtrx call (include/trx.h: trx_eig_backward)
         if Eig.broadening_parameter is not None:
-            F = torch.conj(s) / (torch.abs(s) ** 2 + Eig.broadening_parameter)
-        elif s.dtype == torch.complex64:
-            F = torch.conj(s) / (torch.abs(s) ** 2 + 1.4e-45)
+            eps = float(Eig.broadening_parameter)
         else:
-            F = torch.conj(s) / (torch.abs(s) ** 2 + 4.9e-324)
-        idx = torch.arange(F.shape[-1], device=F.device)
-        F[:, idx, idx] = 0.
-        XH = torch.conj(V).transpose(-2, -1).contiguous()
-        inner = torch.diag_embed(gw) + torch.conj(F) * eng.gemm(XH, gV.contiguous())
-        rhs = eng.gemm(inner, XH)
-        grad = eng.solve(XH, rhs)                                   # (V^H)^-1 (...) V^H
+            eps = 1.4e-45 if w.dtype == torch.complex64 else 4.9e-324
+        grad = eng.eig_backward(w, V, gw.contiguous(), gV.contiguous(), eps)
         if ctx.was_real:
             grad = torch.real(grad)
         return grad if ctx.batched else grad[0]
