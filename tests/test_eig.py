@@ -98,3 +98,16 @@ def test_eig_two_iteration_groups(backend):
     A[8] = np.triu(A[8]) + 1e-6 * A[7] + np.diag(2.0 * np.arange(n))
     w, V, info = run_eig(be, A)
     check(A, w, V, info, 1e-12)
+
+
+@pytest.mark.gpu
+def test_eig_four_iteration_groups_gpu():
+    """batch >= 64: the QR phase runs as four iteration groups on four streams with the 64-wide AED window (the bench shape's
+    code path) -- exercised here at a size the test budget allows."""
+    be = get_backend("gpu")
+    n, batch = 150, 66
+    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
+    for b in range(0, batch, 5):
+        A[b] = 1e-2 * A[b] + np.diag(np.linspace(-3, 3, n)).astype(np.complex128)      # a few fast-converging members per group
+    w, V, info = run_eig(be, A)
+    check(A, w, V, info, 1e-12)
