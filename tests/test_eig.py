@@ -111,3 +111,16 @@ def test_eig_four_iteration_groups_gpu():
         A[b] = 1e-2 * A[b] + np.diag(np.linspace(-3, 3, n)).astype(np.complex128)      # a few fast-converging members per group
     w, V, info = run_eig(be, A)
     check(A, w, V, info, 1e-12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("env", [{"TRX_QR_GROUPS": "3", "TRX_SLAB_SPW": "4"}, {"TRX_QR_GROUPS": "1", "TRX_SLAB_SPW": "1", "TRX_QR_AED": "32"}])
+def test_eig_tuning_knobs(backend, env, monkeypatch):
+    """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window) select different code paths, not results."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    be = get_backend(backend)
+    n, batch = 90, 9
+    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
+    w, V, info = run_eig(be, A)
+    check(A, w, V, info, 1e-12)
