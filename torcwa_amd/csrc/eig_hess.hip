@@ -15,15 +15,17 @@ namespace trx {
 namespace {
 
 constexpr int HNB = EigPlan::HNB;   // panel width
+constexpr int HCT = 512;            // threads of the reflector kernel (one workgroup per matrix; 1024 measured no faster)
+constexpr int HRG = HCT / HNB;      // row groups of its HNB x HRG thread grid
 
 template <class T>
-__global__ __launch_bounds__(512) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int ib, int c,
+__global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int ib, int c,
                                                         cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall,
                                                         cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all) {
     TRX_DYN_SMEM(smem);
     cx<T>* bcol = reinterpret_cast<cx<T>*>(smem);     // [n]   current column (rows p0+1..n-1 at index r-(p0+1))
-    cx<T>* part = bcol + n;                            // [16][HNB] partial sums
-    cx<T>* vec = part + 16 * HNB;                      // [HNB]  t / w vectors
+    cx<T>* part = bcol + n;                            // [HRG][HNB] partial sums
+    cx<T>* vec = part + HRG * HNB;                     // [HNB]  t / w vectors
     T* red = reinterpret_cast<T*>(vec + HNB);          // [16] scalar reduction scratch
     const int b = blockIdx.x;
     cx<T>* A = Aall + (long)b * n * n;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(512) void hess_col_kernel(cx<T>* __restrict__ Aall,
     cx<T>* Tm = Tall + (long)b * HNB * HNB;
     cx<T>* tau = tau_all + (long)b * HNB;
     const int t = threadIdx.x;
-    const int cc = t & (HNB - 1), rg = t / HNB;        // 32 x 16 thread grid
+    const int cc = t & (HNB - 1), rg = t / HNB;        // HNB x HRG thread grid
     const int r0 = p0 + 1;                             // first row of R
     const int nr = n - r0;
 
@@ -43,12 +45,12 @@ __global__ __launch_bounds__(512) void hess_col_kernel(cx<T>* __restrict__ Aall,
         // t[q] = sum_{r > jp} conj(V[r,q]) * V[r,cp],  q < cp
         cx<T> acc(T(0), T(0));
         if (cc < cp)
-            for (int r = jp + 1 + rg; r < n; r += 16) cfma_conj(acc, V[(long)r * HNB + cc], V[(long)r * HNB + cp]);
+            for (int r = jp + 1 + rg; r < n; r += HRG) cfma_conj(acc, V[(long)r * HNB + cc], V[(long)r * HNB + cp]);
         part[rg * HNB + cc] = acc;
         __syncthreads();
         if (t < HNB) {
             cx<T> s(T(0), T(0));
-            for (int g = 0; g < 16; ++g) s += part[g * HNB + t];
+            for (int g = 0; g < HRG; ++g) s += part[g * HNB + t];
             vec[t] = (t < cp) ? s : cx<T>(T(0), T(0));
         }
         __syncthreads();
@@ -88,12 +90,12 @@ __global__ __launch_bounds__(512) void hess_col_kernel(cx<T>* __restrict__ Aall,
         // w = V[R,0:c]^H b
         cx<T> acc(T(0), T(0));
         if (cc < c)
-            for (int i = rg; i < nr; i += 16) cfma_conj(acc, V[(long)(r0 + i) * HNB + cc], bcol[i]);
+            for (int i = rg; i < nr; i += HRG) cfma_conj(acc, V[(long)(r0 + i) * HNB + cc], bcol[i]);
         part[rg * HNB + cc] = acc;
         __syncthreads();
         if (t < HNB) {
             cx<T> s(T(0), T(0));
-            for (int g = 0; g < 16; ++g) s += part[g * HNB + t];
+            for (int g = 0; g < HRG; ++g) s += part[g * HNB + t];
             part[t] = (t < c) ? s : cx<T>(T(0), T(0));       // reuse row 0 of part as w
         }
         __syncthreads();
@@ -221,7 +223,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     const long nn = (long)n * n, sV = (long)n * HNB, sT = HNB * HNB, sW = (long)HNB * n;
     cx<T>*A = B.A, *Z = B.Z, *V = B.Vp, *Y = B.Yp, *Tm = B.Tp, *W = B.W1, *W2 = B.W2;
     TRX_LAUNCH((set_identity_batched<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, Z, n);
-    const size_t sm_col = sizeof(cx<T>) * ((size_t)n + 16 * HNB + HNB) + sizeof(T) * 16;
+    const size_t sm_col = sizeof(cx<T>) * ((size_t)n + HRG * HNB + HNB) + sizeof(T) * 16;
     if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T>, sizeof(cx<T>) * (size_t)n))
         return TRX_ERR_LAUNCH;
     for (int p0 = 0; p0 < n - 2; p0 += HNB) {
@@ -229,7 +231,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
         const int r0 = p0 + 1, nr = n - r0;
         if (hipMemsetAsync(Tm, 0, sizeof(cx<T>) * sT * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
         for (int c = 0; c <= ib; ++c) {
-            TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(512), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau);
+            TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau);
             if (c < ib) {
                 const int j = p0 + c;
                 const int rpb = 64;
