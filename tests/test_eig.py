@@ -124,3 +124,15 @@ def test_eig_tuning_knobs(backend, env, monkeypatch):
     A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
     w, V, info = run_eig(be, A)
     check(A, w, V, info, 1e-12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_nonfinite_input_fails_fast(backend):
+    """A NaN in the input cannot converge: info reports the failure (LAPACK style) instead of iterating to the sweep limit."""
+    be = get_backend(backend)
+    n = 80
+    A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex128)
+    A[1, 3, 5] = np.nan
+    w, V, info = run_eig(be, A)
+    assert info[0] == 0 and info[1] > 0
+    assert np.abs(A[0] @ V[0] - V[0] * w[0][None, :]).max() < 1e-10
