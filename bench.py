@@ -163,8 +163,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
+    for w in range(args.warmup):
+        try:
+            out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
+        except (RuntimeError, torcwa_amd.TrxError) as e:
+            # an untimed warm-up step may hit a device that is still releasing the memory of a previous process: free the
+            # allocator cache, wait and try once more (the timed steps below are never retried)
+            if w > 0:
+                raise
+            print("bench: warm-up step failed (%s); retrying once" % str(e).splitlines()[0], file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            time.sleep(10.0)
+            out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
     barrier()
     # HIP-event timing of the dominant kernels, recorded by libtrx on the launch stream during the timed region
     engine.lib.prof_reset()

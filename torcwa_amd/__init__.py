@@ -11,6 +11,7 @@ from .geometry import geometry, rcwa_geo
 from .rcwa import rcwa
 from .batched import BatchedRCWA
 from .engine import Engine, NumericalError
+from ._lib import TrxError
 
 __version__ = "0.1.0"
-__all__ = ["Eig", "geometry", "rcwa_geo", "rcwa", "BatchedRCWA", "Engine", "NumericalError", "__version__"]
+__all__ = ["Eig", "geometry", "rcwa_geo", "rcwa", "BatchedRCWA", "Engine", "NumericalError", "TrxError", "__version__"]
