@@ -48,13 +48,24 @@ def ref_geometry(nx, ny, Lx, Ly, dtype):
     return g
 
 
+def _via_f32(v):
+    """Round a grid through float32 / complex64 and return it in float64 / complex128 (a float32-representable input)."""
+    if not torch.is_tensor(v):
+        return v
+    return v.to(torch.complex64).to(torch.complex128) if torch.is_complex(v) else v.to(torch.float32).to(torch.float64)
+
+
 def run_case(name, *, freq, order, L, layers, dtype, eps_in=None, eps_out=None, inc=0.0, azi=0.0,
-             angle_layer="input", full_S=False, extra=None, avoid=False):
-    """layers: list of (thickness, eps, mu) with eps/mu python scalars or torch grids."""
-    cdt = torch.complex128 if dtype == "c128" else torch.complex64
-    rdt = torch.float64 if dtype == "c128" else torch.float32
+             angle_layer="input", full_S=False, extra=None, avoid=False, tag=None, max_pinv=0.005):
+    """layers: list of (thickness, eps, mu) with eps/mu python scalars or torch grids.
+    dtype "c128f32": the reference runs in complex128 on grids that were rounded through float32 / complex64, i.e. on exactly
+    the values a complex64 user hands over -- the gate of the complex64-I/O product run (<= 1e-5, no representation slack)."""
+    if dtype == "c128f32":
+        layers = [(d, _via_f32(eps), _via_f32(mu)) for (d, eps, mu) in layers]
+    cdt = torch.complex64 if dtype == "c64" else torch.complex128
+    rdt = torch.float32 if dtype == "c64" else torch.float64
     sim = torcwa.rcwa(freq=freq, order=order, L=L, dtype=cdt, device=torch.device("cpu"),
-                      stable_eig_grad=False, avoid_Pinv_instability=avoid)
+                      stable_eig_grad=False, avoid_Pinv_instability=avoid, max_Pinv_instability=max_pinv)
     if eps_in is not None:
         sim.add_input_layer(eps=eps_in)
     if eps_out is not None:
@@ -138,9 +149,9 @@ def run_case(name, *, freq, order, L, layers, dtype, eps_in=None, eps_out=None, 
     out["diff_inc_deg"], out["diff_azi_deg"] = ia.numpy(), aa.numpy()
     if extra:
         out.update(extra(sim))
-    path = os.path.join(HERE, f"{name}_{dtype}.npz")
+    path = os.path.join(HERE, f"{name}_{tag or dtype}.npz")
     np.savez_compressed(path, **out)
-    print(f"{name}_{dtype}: n={n}  txx00={sp[0, 0, 0]:.12g}  -> {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"{name}_{tag or dtype}: n={n}  txx00={sp[0, 0, 0]:.12g}  -> {os.path.getsize(path) / 1024:.0f} KiB")
     return sim
 
 
@@ -151,8 +162,10 @@ def main():
     eps_si = {532.: complex(nk[-2] ** 2), 650.: complex(nk[-1] ** 2)}
     print("eps_Si(532) =", eps_si[532.], " eps_Si(650) =", eps_si[650.])
 
-    for dtype in ("c128", "c64"):
-        rdt = torch.float64 if dtype == "c128" else torch.float32
+    for dtype in ("c128", "c64", "c128f32"):
+        if "--f32only" in sys.argv and dtype != "c128f32":
+            continue
+        rdt = torch.float32 if dtype == "c64" else torch.float64
         # --- Fresnel, no internal layer (Example0): glass -> air, 0/30/60 degrees ------------
         for ang in (0, 30, 60):
             run_case(f"fresnel_{ang}", freq=1 / 532., order=[2, 2], L=[300., 300.], layers=[], dtype=dtype,
@@ -203,7 +216,7 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__" and "--fields" not in sys.argv and "--grad" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--grad", "--fullsize", "--geometry", "--rayleigh")):
     main()
 
 
@@ -318,3 +331,209 @@ def main_grad():
 
 if __name__ == "__main__" and "--grad" in sys.argv:
     main_grad()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full-size golden vectors: the configs of BASELINE.json at their real Fourier orders
+# ---------------------------------------------------------------------------------------------------------
+def _eps_si_c64(lam):
+    """eps of a-Si:H at `lam` as the complex64 value a complex64 user of the reference computes (Materials.aSiH.apply(l)**2)."""
+    nk = asih_nk([lam])[0]
+    return complex(torch.tensor(nk, dtype=torch.complex64) ** 2)
+
+
+def _grid_c64(dens32, eps_core, eps_bg=1.0):
+    """complex64 permittivity grid exactly as the notebooks build it: geo*eps_core + (1-geo)*eps_bg in complex64 on the CPU."""
+    e = torch.tensor(eps_core, dtype=torch.complex64)
+    return (dens32 * e + (1. - dens32) * eps_bg).to(torch.complex64)
+
+
+def main_fullsize(which):
+    """All inputs are float32 / complex64-representable, so ONE complex128 reference run is the gate of both the complex128
+    product run (<= 1e-9) and the complex64-I/O product run (<= 1e-5)."""
+    g32 = ref_geometry(300, 300, 300., 300., torch.float32)
+    glass = 1.46 ** 2
+    if "config2" in which:
+        # config 2: Example-1 rectangle, one layer, order [15,15], three wavelengths of the 128-point sweep
+        rect = g32.rectangle(Wx=180., Wy=100., Cx=150., Cy=150.)
+        for lam in (400., 532., 700.):
+            eps = _grid_c64(rect, _eps_si_c64(lam))
+            run_case(f"config2_o15_l{int(lam)}", freq=1 / lam, order=[15, 15], L=[300., 300.], dtype="c128f32", tag="c128f32",
+                     layers=[(300., eps, 1.0)], eps_in=glass)
+    if "config4" in which:
+        # config 4: Example-3 style (Wx, Wy, lambda) grid, order [15,15]; a 2 x 2 x 2 corner-ish sample of the 16^3 sweep
+        Wv = np.linspace(50., 250., 16)
+        Lv = np.linspace(400., 700., 16)
+        for iw in (2, 13):
+            for jw in (4, 11):
+                for kl in (1, 14):
+                    wx, wy, lam = float(np.float32(Wv[iw])), float(np.float32(Wv[jw])), float(Lv[kl])
+                    rect = g32.rectangle(Wx=wx, Wy=wy, Cx=150., Cy=150.)
+                    eps = _grid_c64(rect, _eps_si_c64(lam))
+                    run_case(f"config4_o15_w{iw}_{jw}_l{kl}", freq=1 / lam, order=[15, 15], L=[300., 300.], dtype="c128f32", tag="c128f32",
+                             layers=[(300., eps, 1.0)], eps_in=glass,
+                             extra=lambda sim, wx=wx, wy=wy, lam=lam: {"Wx": np.float64(wx), "Wy": np.float64(wy), "lam": np.float64(lam)})
+    if "config3" in which:
+        # config 3: the literal 6-layer stack of Example1-1 (3 rotated rectangles in SU8 + 3 SU8 spacers), order [8,8]
+        su8 = 1.6 ** 2
+        for lam in (650., 500.):
+            lays = []
+            for th in (0., 30., 60.):
+                r = g32.rectangle(Wx=180., Wy=100., Cx=150., Cy=150., theta=th / 180 * np.pi)
+                lays.append((200., _grid_c64(r, _eps_si_c64(lam), su8), 1.0))
+                lays.append((100., su8, 1.0))
+            run_case(f"config3_o8_l{int(lam)}", freq=1 / lam, order=[8, 8], L=[300., 300.], dtype="c128f32", tag="c128f32",
+                     layers=lays, eps_in=glass)
+    if "config5" in which:
+        main_config5()
+
+
+def config5_density(nx=700, ny=300, beta=6.0):
+    """Deterministic stand-in for Example 6's blurred, tanh-projected random density (the notebook draws it on the CUDA RNG,
+    which is not reproducible): a closed-form sum of cosines, symmetric under y -> Ly - y like the notebook's (rho + fliplr)/2,
+    projected with the notebook's tanh formula, rounded to float32.  tests/helpers.py holds the same recipe."""
+    x = (np.arange(nx) + 0.5) / nx
+    y = (np.arange(ny) + 0.5) / ny
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    f = (0.50 + 0.22 * np.cos(2 * np.pi * (1 * X) + 0.3) * np.cos(2 * np.pi * 1 * Y) + 0.17 * np.cos(2 * np.pi * (2 * X) + 1.1)
+         + 0.12 * np.cos(2 * np.pi * (3 * X) + 2.0) * np.cos(2 * np.pi * 2 * Y) + 0.08 * np.cos(2 * np.pi * (5 * X) + 0.7) * np.cos(2 * np.pi * 1 * Y))
+    rho = 0.5 + np.tanh(2 * beta * f - beta) / (2 * np.tanh(beta))
+    return rho.astype(np.float32)
+
+
+def main_config5():
+    """config 5: Example-6 geometry L=[700,300], 700x300 grid, order [15,8] (the notebook's own order), complex128,
+    FoM = sum over the four polarisation pairs of |t_(1,0)|^2, gradient w.r.t. the density through the stabilised Eig."""
+    lam = 532.
+    eps_si = complex(asih_nk([lam])[0] ** 2)
+    rho0 = torch.from_numpy(config5_density().astype(np.float64))
+    out = {"eps_si": np.complex128(eps_si), "rho_sum": np.float64(rho0.sum()), "rho_sub": rho0[::70, ::30].numpy(), "lam": np.float64(lam)}
+    torcwa.Eig.broadening_parameter = 1e-10
+    rho = rho0.clone().requires_grad_(True)
+    sim = torcwa.rcwa(freq=1 / lam, order=[15, 8], L=[700., 300.], dtype=torch.complex128, device=torch.device("cpu"), stable_eig_grad=True)
+    sim.add_input_layer(eps=1.46 ** 2)
+    sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+    sim.add_layer(thickness=300., eps=rho * eps_si + (1. - rho))
+    sim.solve_global_smatrix()
+    ts = {p: sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization=p, ref_order=[0, 0]) for p in ("xx", "yy", "xy", "yx")}
+    fom = sum(torch.abs(t) ** 2 for t in ts.values())
+    fom.sum().backward()
+    gr = rho.grad.numpy()
+    out.update(fom=fom.detach().numpy(), grad_sum=np.float64(gr.sum()), grad_l2=np.float64(np.linalg.norm(gr)), grad_sub=gr[::7, ::3].copy(),
+               **{f"t1{p}": t.detach().numpy() for p, t in ts.items()})
+    lam2 = sim.kz_norm[0].detach().numpy() ** 2
+    out["L0_kz2_sorted"] = lam2[np.lexsort((lam2.imag, lam2.real))]
+    np.savez_compressed(os.path.join(HERE, "config5_o15_8_c128.npz"), **out)
+    print("config5_o15_8: FoM", float(fom), "sum grad", gr.sum(), "|grad|", np.linalg.norm(gr))
+
+
+if __name__ == "__main__" and "--fullsize" in sys.argv:
+    sel = [a for a in sys.argv[1:] if a.startswith("config")] or ["config2", "config3", "config4", "config5"]
+    main_fullsize(sel)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# geometry / return_layer / material-table golden vectors (SURVEY.md 8(f) ranks 2-4)
+# ---------------------------------------------------------------------------------------------------------
+def main_geometry():
+    out = {}
+    kw = dict(Lx=320., Ly=210., nx=48, ny=40, edge_sharpness=37.)
+    calls = [("circle", dict(R=60., Cx=150., Cy=100.)), ("ellipse", dict(Rx=90., Ry=40., Cx=170., Cy=90., theta=0.4)),
+             ("square", dict(W=110., Cx=140., Cy=120., theta=0.2)), ("rectangle", dict(Wx=180., Wy=70., Cx=160., Cy=105., theta=-0.7)),
+             ("rhombus", dict(Wx=200., Wy=120., Cx=150., Cy=100., theta=0.3)),
+             ("super_ellipse", dict(Wx=190., Wy=100., Cx=155., Cy=95., theta=0.5, power=3.))]
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        g = torcwa.geometry(dtype=dt, device=torch.device("cpu"), **kw)
+        g.grid()
+        out[f"x_{tag}"], out[f"y_{tag}"] = g.x.numpy(), g.y.numpy()
+        shapes = {}
+        for nm, a in calls:
+            shapes[nm] = getattr(g, nm)(**a)
+            out[f"inst_{nm}_{tag}"] = shapes[nm].numpy()
+        out[f"inst_union_{tag}"] = g.union(shapes["circle"], shapes["rectangle"]).numpy()
+        out[f"inst_intersection_{tag}"] = g.intersection(shapes["ellipse"], shapes["rhombus"]).numpy()
+        out[f"inst_difference_{tag}"] = g.difference(shapes["square"], shapes["circle"]).numpy()
+        # legacy class-level API (the notebooks' torcwa.rcwa_geo)
+        G = torcwa.rcwa_geo
+        G.dtype, G.device = dt, torch.device("cpu")
+        G.Lx, G.Ly, G.nx, G.ny, G.edge_sharpness = kw["Lx"], kw["Ly"], kw["nx"], kw["ny"], kw["edge_sharpness"]
+        G.grid()
+        cs = {}
+        for nm, a in calls:
+            cs[nm] = getattr(G, nm)(**a)
+            out[f"cls_{nm}_{tag}"] = cs[nm].numpy()
+        out[f"cls_union_{tag}"] = G.union(cs["circle"], cs["rectangle"]).numpy()
+        out[f"cls_intersection_{tag}"] = G.intersection(cs["ellipse"], cs["rhombus"]).numpy()
+        out[f"cls_difference_{tag}"] = G.difference(cs["square"], cs["circle"]).numpy()
+    np.savez_compressed(os.path.join(HERE, "geometry_shapes.npz"), **out)
+    print("geometry_shapes:", len(out), "arrays")
+
+    # return_layer (rcwa.py:264-298) of the asymmetric case (patterned eps AND mu) on a 21 x 17 grid and the default 100 x 100
+    z = np.load(os.path.join(HERE, "asym_o32_c128.npz"))
+    sim = torcwa.rcwa(freq=float(z["freq"]), order=[3, 2], L=[320., 410.], dtype=torch.complex128, device=torch.device("cpu"))
+    sim.add_input_layer(eps=2.1)
+    sim.set_incident_angle(inc_ang=0.1, azi_ang=0.2)
+    sim.add_layer(thickness=150., eps=torch.from_numpy(z["L0_eps_grid"]), mu=torch.from_numpy(z["L0_mu_grid"]))
+    sim.add_layer(thickness=80., eps=2.25)
+    o = {}
+    for nm, (nx, ny) in (("a", (21, 17)), ("b", (100, 100))):
+        e, m = sim.return_layer(0, nx=nx, ny=ny)
+        o[f"L0_eps_{nm}"], o[f"L0_mu_{nm}"] = e.numpy(), m.numpy()
+    e, m = sim.return_layer(1, nx=21, ny=17)
+    o["L1_eps_a"], o["L1_mu_a"] = e.numpy(), m.numpy()
+    np.savez_compressed(os.path.join(HERE, "return_layer_asym_o32.npz"), **o)
+
+    # material helper (example/Materials.py:5-52): n+ik at in-range, out-of-range and knot wavelengths, in both dtypes, and the
+    # finite-difference derivative its backward uses
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "example"))
+    sys.path.insert(0, os.path.join(REF, "example"))
+    import Materials
+    lams = np.concatenate([[150., 191.9, 192., 192.003, 192.5, 193., 400.25, 532., 650.123, 998., 998.997, 999., 1200.], np.linspace(200.3, 990.7, 40)])
+    nk128, nk64, dn = [], [], []
+    for lam in lams:
+        w = torch.tensor(float(lam), dtype=torch.float64, requires_grad=True)
+        v = Materials.aSiH.apply(w)
+        nk128.append(complex(v))
+        (v.real * 2.0 + v.imag * 3.0).backward()
+        dn.append(float(w.grad))
+        nk64.append(complex(Materials.aSiH.apply(torch.tensor(float(lam), dtype=torch.float32))))
+    os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "material_asih.npz"), lam=lams, nk128=np.array(nk128), nk64=np.array(nk64, dtype=np.complex64),
+                        grad_2re_3im=np.array(dn))
+    print("material_asih:", len(lams), "wavelengths")
+
+
+if __name__ == "__main__" and "--geometry" in sys.argv:
+    main_geometry()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Rayleigh anomaly (kz -> 0 of a diffraction order, rcwa.py:1143-1147, 1262): just off and exactly on the anomaly
+# ---------------------------------------------------------------------------------------------------------
+def main_rayleigh():
+    lam_tab = np.load(os.path.join(HERE, "asih_table.npz"))
+    eps_si = complex(lam_tab["nk"][-2]) ** 2
+    g = ref_geometry(64, 64, 300., 300., torch.float64)
+    rect = g.rectangle(Wx=180., Wy=100., Cx=150., Cy=150.)
+    eps1 = rect * eps_si + (1. - rect)
+    # free-space order (1,0) grazes at lambda = L = 300 nm under normal incidence: Kz0 = sqrt(1 - (lambda/L)^2)
+    for tag, lam in (("above", 300.0001), ("below", 299.9999)):
+        run_case(f"rayleigh_{tag}", freq=1 / lam, order=[3, 3], L=[300., 300.], dtype="c128", layers=[(300., eps1, 1.0)], eps_in=1.46 ** 2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sim = run_case("rayleigh_exact", freq=1 / 300., order=[3, 3], L=[300., 300.], dtype="c128", layers=[(300., eps1, 1.0)], eps_in=1.46 ** 2)
+    print("exact anomaly: non-finite entries of S11:", int((~torch.isfinite(torch.view_as_real(sim.S[0]))).sum()), "of", sim.S[0].numel() * 2)
+
+
+    # avoid_Pinv_instability with a threshold below the rounding noise of P P^-1: the reference takes its V = Q W Kz^-1 branch
+    # (rcwa.py:1259-1262) on every layer -- the fixture that exercises that branch
+    z = np.load(os.path.join(HERE, "asym_o32_c128.npz"))
+    lays = [(150., torch.from_numpy(z["L0_eps_grid"]), torch.from_numpy(z["L0_mu_grid"])), (80., 2.25, 1.0), (120., torch.from_numpy(z["L2_eps_grid"]), 1.0)]
+    run_case("asym_o32_forceQ", freq=1 / 600., order=[3, 2], L=[320., 410.], dtype="c128", layers=lays, eps_in=2.1, eps_out=1.7,
+             inc=20 * np.pi / 180, azi=35 * np.pi / 180, angle_layer="output", avoid=True, max_pinv=1e-17, full_S=True)
+
+
+if __name__ == "__main__" and "--rayleigh" in sys.argv:
+    main_rayleigh()

@@ -65,3 +65,15 @@ def multiset_dist(a, b):
         worst = max(worst, abs(b[j] - z))
         b.pop(j)
     return worst / max(np.abs(a).max(), 1e-300)
+
+
+def config5_density(nx=700, ny=300, beta=6.0):
+    """Deterministic stand-in for Example 6's blurred, tanh-projected random density (same recipe as
+    tests/golden/make_golden.py:config5_density; the fixture stores a checksum and a sub-sample of it)."""
+    x = (np.arange(nx) + 0.5) / nx
+    y = (np.arange(ny) + 0.5) / ny
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    f = (0.50 + 0.22 * np.cos(2 * np.pi * (1 * X) + 0.3) * np.cos(2 * np.pi * 1 * Y) + 0.17 * np.cos(2 * np.pi * (2 * X) + 1.1)
+         + 0.12 * np.cos(2 * np.pi * (3 * X) + 2.0) * np.cos(2 * np.pi * 2 * Y) + 0.08 * np.cos(2 * np.pi * (5 * X) + 0.7) * np.cos(2 * np.pi * 1 * Y))
+    rho = 0.5 + np.tanh(2 * beta * f - beta) / (2 * np.tanh(beta))
+    return rho.astype(np.float32)

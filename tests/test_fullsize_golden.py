@@ -1,0 +1,123 @@
+"""Parity at the REAL sizes of BASELINE.json's configs against the reference itself.
+
+Fixtures `tests/golden/config*_c128f32.npz` / `config5_o15_8_c128.npz` hold the output of the real reference (imported in the
+build container, `make_golden.py --fullsize`) run in complex128 on float32 / complex64-representable inputs:
+
+  config 2  Example-1 rectangle, 1 layer, order [15,15] (n = 1922), lambda = 400 / 532 / 700 nm of the 128-point sweep
+  config 3  the literal 6-layer Example1-1 stack (3 rotated rectangles + 3 SU8 spacers), order [8,8], lambda = 650 / 500 nm
+  config 4  Example-3 style (Wx, Wy, lambda) grid, order [15,15]: a 2 x 2 x 2 sample of the 16^3 sweep, ALSO solved as one
+            batch with per-point geometry (the batched sweep driver against the reference's per-point loop)
+  config 5  Example-6 geometry (L = [700,300], 700 x 300 grid), order [15,8], FoM = sum_pol |t_(1,0)|^2 and dFoM/d(density)
+            through the stabilised Eig backward
+
+Gates: complex128 run <= 1e-9, complex64-I/O run <= 1e-5 (north_star), gradient <= 1e-6 -- all against the reference's
+complex128 output on identical inputs.  `-m "not gpu"`: the CPU oracle is held to the same fixtures (pins the oracle at full size).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, case_inputs, config5_density, load_case, multiset_dist, relerr
+from tests.test_pipeline import check_against_golden, make_engine, run_case
+
+FULL = sorted(os.path.basename(p)[:-len("_c128f32.npz")] for p in glob.glob(os.path.join(GOLDEN, "config[234]_*_c128f32.npz")))
+CONFIG4 = [c for c in FULL if c.startswith("config4")]
+
+
+def test_fixture_inventory():
+    assert len([c for c in FULL if c.startswith("config2")]) == 3 and len(CONFIG4) == 8 and len([c for c in FULL if c.startswith("config3")]) == 2
+    assert os.path.exists(os.path.join(GOLDEN, "config5_o15_8_c128.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-9), ("c64", 1e-5)])
+@pytest.mark.parametrize("name", FULL)
+def test_fullsize_against_reference(name, dtype, tol):
+    eng = make_engine("gpu")
+    g = load_case(name, "c128f32")
+    sim = run_case(eng, g, dtype)
+    check_against_golden(sim, g, dtype, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-9), ("c64", 1e-5)])
+def test_config4_batched_geometry_sweep(dtype, tol):
+    """The 8 (Wx, Wy, lambda) points as ONE batch with per-point permittivity grids and frequencies through the sweep driver:
+    every S-parameter probe of every point against the reference's per-point loop (example/Example3.ipynb:92-101)."""
+    from torcwa_amd.sweep import solve_stack_sweep
+    from tests.helpers import ORDERS_PROBE
+    eng = make_engine("gpu")
+    gs = [load_case(c, "c128f32") for c in CONFIG4]
+    cdt = torch.complex128 if dtype == "c128" else torch.complex64
+    grids = torch.stack([torch.from_numpy(g["L0_eps_grid"]).to(cdt) for g in gs]).to(eng.device)
+    freq = torch.tensor([float(g["freq"]) for g in gs], dtype=torch.float64, device=eng.device)
+    for pol, b in (("xx", 0), ("yy", 3), ("ps", 6)):
+        for chunk in ((8, 3) if pol == "xx" else (8,)):        # ragged chunks: 3 + 3 + 2
+            got = solve_stack_sweep(freq, [(300., grids)], [15, 15], [300., 300.], eps_in=1.46 ** 2, dtype=cdt, engine=eng, chunk=chunk,
+                                    orders=[tuple(o) for o in ORDERS_PROBE[:7]], polarization=pol).cpu().numpy()
+            ref = np.stack([g["sparams"][0, b, :7] for g in gs])
+            assert got.dtype == (np.complex128 if dtype == "c128" else np.complex64)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < tol, (pol, chunk)
+
+
+@pytest.mark.gpu
+def test_config5_fom_and_gradient():
+    import torcwa_amd
+    eng = make_engine("gpu")
+    g = np.load(os.path.join(GOLDEN, "config5_o15_8_c128.npz"))
+    rho_np = config5_density().astype(np.float64)
+    assert abs(rho_np.sum() - float(g["rho_sum"])) < 1e-6 and np.abs(rho_np[::70, ::30] - g["rho_sub"]).max() < 1e-12
+    eps_si = complex(g["eps_si"])
+    rho = torch.from_numpy(rho_np).to(eng.device).requires_grad_(True)
+    old = torcwa_amd.Eig.broadening_parameter
+    torcwa_amd.Eig.broadening_parameter = 1e-10
+    try:
+        sim = torcwa_amd.rcwa(freq=1 / float(g["lam"]), order=[15, 8], L=[700., 300.], dtype=torch.complex128, engine=eng, stable_eig_grad=True)
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        sim.add_layer(thickness=300., eps=rho * eps_si + (1. - rho))
+        sim.solve_global_smatrix()
+        ts = {p: sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization=p, ref_order=[0, 0]) for p in ("xx", "yy", "xy", "yx")}
+        fom = sum(torch.abs(t) ** 2 for t in ts.values())
+        fom.sum().backward()
+    finally:
+        torcwa_amd.Eig.broadening_parameter = old
+    for p, t in ts.items():
+        ref = complex(np.asarray(g[f"t1{p}"]).reshape(-1)[0])
+        assert abs(complex(t.detach().reshape(-1)[0]) - ref) / max(abs(ref), 1e-3) < 1e-9, p
+    fref = float(np.asarray(g["fom"]).reshape(-1)[0])
+    assert abs(float(fom.detach().reshape(-1)[0]) - fref) / fref < 1e-9
+    gr = rho.grad.cpu().numpy()
+    scale = np.abs(g["grad_sub"]).max()
+    assert np.abs(gr[::7, ::3] - g["grad_sub"]).max() / scale < 1e-6
+    assert abs(gr.sum() - float(g["grad_sum"])) / abs(float(g["grad_sum"])) < 1e-6
+    assert abs(np.linalg.norm(gr) - float(g["grad_l2"])) / float(g["grad_l2"]) < 1e-6
+    lam2 = (sim.kz_norm[0].detach().cpu().numpy().astype(np.complex128)) ** 2
+    assert multiset_dist(lam2, g["L0_kz2_sorted"]) < 1e-8
+
+
+# ---- the CPU oracle against the same full-size fixtures (pins the checker where the GPU parity tests use it) -------------------
+def _oracle_case(g, dtype=torch.complex128):
+    from oracle import rcwa_oracle as orc
+    ci = case_inputs(g, "c128")
+    s, lays, S, C = orc.solve_stack(ci["freq"], ci["order"], ci["L"], [(d, e, m) for d, e, m in ci["layers"]], dtype=dtype, eps_in=ci.get("eps_in"))
+    return orc, s, lays, S
+
+
+@pytest.mark.parametrize("name", ["config2_o15_l532", "config3_o8_l650"])
+def test_oracle_pinned_at_full_size(name):
+    from tests.helpers import DIRPORT, ORDERS_PROBE, POLS
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    g = load_case(name, "c128f32")
+    orc, s, lays, S = _oracle_case(g)
+    cidx = g["central_idx"]
+    for k in range(4):
+        assert relerr(S[k].numpy()[np.ix_(cidx, cidx)], g[f"S{k}_central"]) < 1e-9, k
+    assert np.allclose([np.linalg.norm(x.numpy()) for x in S], g["S_fro"], rtol=1e-9)
+    for a, (dr, pt) in enumerate(DIRPORT[:2]):
+        for b, pol in enumerate(POLS):
+            v = orc.s_parameters(s, S, ORDERS_PROBE, direction=dr, port=pt, polarization=pol).numpy()
+            assert np.abs(v - g["sparams"][a, b]).max() / max(np.abs(g["sparams"][a, b]).max(), 1e-3) < 1e-9, (dr, pt, pol)

@@ -25,6 +25,8 @@ def make_engine(backend):
 
 
 def run_case(eng, g, dtype, **kw):
+    """Build the drop-in simulation of golden case `g` (inputs in complex128 as stored; a complex64 run hands the float32 /
+    complex64 casts of the grids, which are exact for the *_c128f32 fixtures)."""
     import torcwa_amd
     ci = case_inputs(g, "c128")
     sim_dtype = torch.complex128 if dtype == "c128" else torch.complex64
@@ -53,13 +55,15 @@ def test_against_reference_golden(backend, name, dtype, tol):
     if backend == "emu" and (name not in EMU_CASES or (dtype == "c64" and name != "asym_o32")):
         pytest.skip("emulator runs the small cases only")
     eng = make_engine(backend)
-    g = load_case(name, "c128")                       # c128 reference output is the gate for both dtypes
+    # The complex128 reference output is the gate for both dtypes.  The complex64-I/O run is held to north_star's 1e-5 against
+    # the reference run in complex128 on the SAME float32-representable grids (*_c128f32 fixtures): identical inputs, no slack.
+    g = load_case(name, "c128" if dtype == "c128" else "c128f32")
     avoid = name.endswith("avoidPinv")
     sim = run_case(eng, g, dtype, avoid_Pinv_instability=avoid)
-    if dtype == "c64":
-        # the float32 grid itself differs from the float64 one by ~6e-8 relative: an input-representation effect
-        # shared with the reference; parity is stated for identical (c128-representable) inputs, so allow for it
-        tol = 2e-5
+    check_against_golden(sim, g, dtype, tol, avoid=avoid)
+
+
+def check_against_golden(sim, g, dtype, tol, avoid=False):
     S = [s.cpu().numpy() for s in sim.S]
     assert S[0].dtype == (np.complex128 if dtype == "c128" else np.complex64)
     fro = np.array([np.linalg.norm(x) for x in S])
@@ -89,7 +93,11 @@ def test_against_reference_golden(backend, name, dtype, tol):
             for k in range(4):
                 assert relerr(sim.Sout[k].cpu().numpy(), g[f"Sout{k}"]) < (1e-12 if dtype == "c128" else 1e-6)
     if avoid:
-        assert np.allclose(float(sim.Pinv_instability[0]), g["Pinv_instability"][0], rtol=0.5)
+        # max |P P^-1 - I| is a rounding-noise figure (~1e-13 here): its value depends on the elimination order of the inverse,
+        # so the parity statement is "same decision, same magnitude class", plus an exact check on a deliberately
+        # ill-conditioned P in test_aux_rows.py::test_pinv_instability_metric (rtol 1e-3)
+        got, ref = float(sim.Pinv_instability[0]), float(g["Pinv_instability"][0])
+        assert (got >= 0.005) == (ref >= 0.005) and got < max(100 * ref, 1e-10)
     # S-parameters: 8 polarisations x 4 (direction, port) x probe orders (the last probe order is clamped)
     sp = g["sparams"]
     for a, (dr, pt) in enumerate(DIRPORT):

@@ -8,10 +8,11 @@ built by `python torcwa_amd/csrc/build.py`).  There is no CPU fallback.
 """
 from .torch_eig import Eig
 from .geometry import geometry, rcwa_geo
+from . import materials
 from .rcwa import rcwa
 from .batched import BatchedRCWA
 from .engine import Engine, NumericalError
 from ._lib import TrxError
 
 __version__ = "0.1.0"
-__all__ = ["Eig", "geometry", "rcwa_geo", "rcwa", "BatchedRCWA", "Engine", "NumericalError", "TrxError", "__version__"]
+__all__ = ["Eig", "geometry", "rcwa_geo", "rcwa", "BatchedRCWA", "Engine", "NumericalError", "TrxError", "materials", "__version__"]

@@ -220,15 +220,11 @@ class BatchedRCWA:
             kz = torch.cat((kz, kz), dim=1)
         else:                                                                           # rcwa.py:1224-1242
             if diff:
-                old_bp = Eig.broadening_parameter
-                if not self.stable_eig_grad:      # reference: plain torch.linalg.eig backward (no broadening)
-                    Eig.broadening_parameter = None
                 Eig.engine = eng
-                try:
-                    lam, W = Eig.apply(ag.GemmFn.apply(P, Q, eng))
-                finally:
-                    Eig.broadening_parameter = old_bp
-                self._eig_bp = None if not self.stable_eig_grad else "global"
+                A = ag.GemmFn.apply(P, Q, eng)
+                # stable_eig_grad=False is the reference's plain torch.linalg.eig branch (rcwa.py:1238): its backward is never
+                # broadened.  The choice is bound to this graph node (not to the process-global at backward time).
+                lam, W = Eig.apply(A) if self.stable_eig_grad else Eig.apply(A, Eig.UNBROADENED)
             else:
                 # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
                 A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
@@ -288,6 +284,19 @@ class BatchedRCWA:
         P, W, kz, d = self.P[-1], self.E_eigvec[-1], self.kz_norm[-1], self.thickness[-1]
         X = torch.exp(1j * (self.omega * d)[:, None] * kz)                              # [B, n]
         V = ag.SolveFn.apply(P, W * kz[:, None, :], eng)                                # P^-1 W Kz
+        if self.avoid_Pinv_instability:                                                 # rcwa.py:1249-1262 (metrics are detached diagnostics)
+            with torch.no_grad():
+                Pd, Qd = P.detach(), self.Q[-1].detach()
+                I = torch.eye(n, dtype=self._cdtype, device=self._device)
+                Pinv = eng.inverse(Pd)
+                ins = torch.maximum(torch.amax(torch.abs(eng.gemm(Pd, Pinv) - I), dim=(1, 2)),
+                                    torch.amax(torch.abs(eng.gemm(Pinv, Pd) - I), dim=(1, 2)))
+                qins = torch.amax(torch.abs(eng.gemm(Qd, eng.inverse(Qd)) - I), dim=(1, 2))
+            self.Pinv_instability.append(ins)
+            self.Qinv_instability.append(qins)
+            bad = ins >= self.max_Pinv_instability
+            if bool(bad.any()):                                                         # V = Q W Kz^-1 for the ill-conditioned points
+                V = torch.where(bad[:, None, None], ag.GemmFn.apply(self.Q[-1], (W / kz[:, None, :]).contiguous(), eng), V)
         p11, p12, p21, p22 = [t.to(self._cdtype)[:, :, None] for t in self._Vfinv.d]
         F = torch.cat((p11 * V[:, :N] + p12 * V[:, N:], p21 * V[:, :N] + p22 * V[:, N:]), dim=1)    # Vf^-1 V
         A_, B_ = W + F, (W - F) * X[:, None, :]

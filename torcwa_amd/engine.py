@@ -6,6 +6,7 @@ HIP stream to libtrx.  There is no CPU fallback: the default engine binds torcwa
 a CUDA/ROCm device.  (The test-suite can inject the kernel-logic emulator build with host tensors; see tests/.)
 """
 import ctypes
+import threading
 
 import torch
 
@@ -32,7 +33,7 @@ class Engine:
         self.lib = lib
         self.device = torch.device(device if device is not None else "cpu")
         self.check_info = True
-        self._fail_acc = None          # device-side count of non-zero info entries seen while check_info is False
+        self._fail_acc = {}            # per host thread: device-side count of non-zero info entries seen while check_info is False
 
     # -- helpers ---------------------------------------------------------------------------------------
     @property
@@ -52,15 +53,31 @@ class Engine:
         return t if t.is_contiguous() else t.contiguous()
 
     def failures(self):
-        """Number of batch entries that reported a numerical failure since the last call (one host sync)."""
-        n = 0 if self._fail_acc is None else int(self._fail_acc)
-        self._fail_acc = None
-        return n
+        """Number of batch entries that reported a numerical failure since the last call (one device sync).  The counters are
+        kept per host thread (each thread accumulates on its own stream); they are combined here after a device-wide sync."""
+        acc, self._fail_acc = self._fail_acc, {}
+        if not acc:
+            return 0
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return sum(int(c) for c in acc.values())
+
+    def _check(self, *tensors):
+        """Raw pointers carry no type information: refuse operands on another device or of mixed / non-complex dtypes here,
+        instead of an invalid device access or garbage inside the kernel."""
+        dt = tensors[0].dtype
+        for t in tensors:
+            if t.device != self.device and not (t.device.type == self.device.type and self.device.index is None):
+                raise ValueError(f"libtrx operand on {t.device}, engine on {self.device}")
+            if t.dtype != dt or dt not in _CODE:
+                raise TypeError(f"libtrx operands must share one complex dtype (got {[str(x.dtype) for x in tensors]})")
 
     def _info(self, info, what):
         if not self.check_info:        # deferred, sync-free accounting (throughput runs); read with failures()
             c = (info != 0).sum()
-            self._fail_acc = c if self._fail_acc is None else self._fail_acc + c
+            tid = threading.get_ident()
+            prev = self._fail_acc.get(tid)
+            self._fail_acc[tid] = c if prev is None else prev + c
             return
         if self.check_info:
             bad = int((info != 0).sum())
@@ -86,6 +103,7 @@ class Engine:
     def gemm(self, A, Bm, *, opA=0, opB=0, alpha=1.0, beta=0.0, out=None):
         """Batched C = alpha op(A) op(B) + beta C for contiguous [B,*,*] operands."""
         A, Bm = self._c(A), self._c(Bm)
+        self._check(A, Bm)
         dt = A.dtype
         Bt = A.shape[0]
         m = A.shape[1] if opA == 0 else A.shape[2]
@@ -103,6 +121,7 @@ class Engine:
 
     def inverse(self, A):
         """Returns inv(A) for [B,n,n] (A is not modified)."""
+        self._check(A)
         A = A.clone()
         B, n, _ = A.shape
         piv, info = self._ints(B * n), self._ints(B)
@@ -114,6 +133,7 @@ class Engine:
 
     def solve(self, A, Bm):
         """Returns X with A X = B ([B,n,n], [B,n,r]); inputs are not modified."""
+        self._check(A, Bm)
         A, X = A.clone(), Bm.clone()
         B, n, _ = A.shape
         piv, info = self._ints(B * n), self._ints(B)
@@ -124,6 +144,7 @@ class Engine:
     # -- a7 --------------------------------------------------------------------------------------------
     def eig(self, A, destroy=False):
         """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14)."""
+        self._check(A)
         A = self._c(A) if destroy else A.clone()
         B, n, _ = A.shape
         dt = A.dtype

@@ -60,7 +60,11 @@ class FieldMixin:
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _mm(self, A, B):
-        """[r,k] @ [k,c] on the HIP GEMM."""
+        """[r,k] @ [k,c] on the HIP GEMM; through the autograd wrapper when the simulation was built on the differentiable
+        path, so that field-based figures of merit can be back-propagated like in the reference (plain torch ops there)."""
+        if getattr(self._b, "_diff", False) and (A.requires_grad or B.requires_grad):
+            from . import autograd_ops as ag
+            return ag.GemmFn.apply(A[None].contiguous(), B[None].contiguous(), self._b.engine)[0]
         return self._b.engine.gemm(A[None].contiguous(), B[None].contiguous())[0]
 
     def _bd_apply(self, bd, X):
@@ -154,7 +158,11 @@ class FieldMixin:
         key = (layer_num, id(self._b.eps_conv[layer_num]))
         if key not in cache:
             eng = self._b.engine
-            cache[key] = (eng.inverse(self._b.eps_conv[layer_num])[0], eng.inverse(self._b.mu_conv[layer_num])[0])
+            E, M = self._b.eps_conv[layer_num], self._b.mu_conv[layer_num]
+            if getattr(self._b, "_diff", False) and (E.requires_grad or M.requires_grad):
+                from . import autograd_ops as ag
+                return ag.InverseFn.apply(E, eng)[0], ag.InverseFn.apply(M, eng)[0]      # graph-bound: not cached
+            cache[key] = (eng.inverse(E)[0], eng.inverse(M)[0])
         return cache[key]
 
     def _plane(self, which, axis, z_axis, fixed):

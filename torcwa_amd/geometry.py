@@ -78,11 +78,8 @@ class geometry:
         return torch.minimum(A, 1. - B)
 
 
-class _ClassLevel(type):
-    """Lets `rcwa_geo.Lx = ...; rcwa_geo.rectangle(...)` work on the class itself, like the reference's legacy API."""
-
-
-class rcwa_geo(metaclass=_ClassLevel):
+class rcwa_geo:
+    """Legacy class-level API of the notebooks: `rcwa_geo.Lx = ...; rcwa_geo.grid(); rcwa_geo.rectangle(...)` on the class itself."""
     dtype = torch.float32
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     Lx, Ly, nx, ny = 1., 1., 100, 100

@@ -71,23 +71,28 @@ class rcwa(FieldMixin):
         return self._b._matching_indices(orders)
 
     def return_layer(self, layer_num, nx=100, ny=100):                                  # rcwa.py:264-298
-        """eps(x,y), mu(x,y) of a layer recovered from the truncated Fourier series held in its convolution matrix."""
+        """eps(x,y), mu(x,y) of a layer recovered from the truncated Fourier series held in its convolution matrix.
+        Harmonic (i, j), |i| <= 2ox, |j| <= 2oy, is read from the first column / first row of the Toeplitz matrix and
+        placed at [i mod nx, j mod ny] (the reference's negative-index wrap); one gather + one inverse FFT per material."""
+        import numpy as np
         ox, oy = self.order
         wy = 2 * oy + 1
+        if 2 * ox >= nx or 2 * oy >= ny:
+            raise IndexError("index %d is out of bounds for a %d x %d grid" % (2 * max(ox, oy), nx, ny))
+        i, j = np.broadcast_arrays(np.arange(-2 * ox, 2 * ox + 1)[:, None], np.arange(-2 * oy, 2 * oy + 1)[None, :])
+        row = np.where(i >= 0, np.where(j >= 0, i * wy + j, i * wy), np.where(j >= 0, j, 0)).ravel()
+        col = np.where(i >= 0, np.where(j >= 0, 0, -j), np.where(j >= 0, -i * wy, -i * wy - j)).ravel()
+        flat = ((i % nx) * ny + (j % ny)).ravel()
+        # a coarse grid (nx < 4ox+1) makes harmonics collide: the reference's loop order lets the LAST write win
+        _, first_rev = np.unique(flat[::-1], return_index=True)
+        keep = np.sort(len(flat) - 1 - first_rev)
+        dev = self._device
+        row_t, col_t, flat_t = (torch.as_tensor(a[keep], dtype=torch.int64, device=dev) for a in (row, col, flat))
         outs = []
         for conv in (self._b.eps_conv[layer_num][0], self._b.mu_conv[layer_num][0]):
-            f = torch.zeros([nx, ny], dtype=conv.dtype, device=self._device)
-            for i in range(-2 * ox, 2 * ox + 1):
-                for j in range(-2 * oy, 2 * oy + 1):
-                    if i >= 0 and j >= 0:
-                        f[i, j] = conv[i * wy + j, 0]
-                    elif i >= 0 and j < 0:
-                        f[i, j] = conv[i * wy, -j]
-                    elif i < 0 and j >= 0:
-                        f[i, j] = conv[j, -i * wy]
-                    else:
-                        f[i, j] = conv[0, -i * wy - j]
-            outs.append((torch.fft.ifftn(f) * nx * ny).to(self._dtype))
+            f = torch.zeros(nx * ny, dtype=conv.dtype, device=dev)
+            f[flat_t] = conv[row_t, col_t]
+            outs.append((torch.fft.ifftn(f.reshape(nx, ny)) * nx * ny).to(self._dtype))
         return outs[0], outs[1]
 
     # ---- un-batched attribute views ----------------------------------------------------------------------------

@@ -62,7 +62,6 @@ def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtyp
                  polarization, direction, port, check_info):
     """layers: list of (thickness, eps[, mu]); thickness scalar or [b]; eps/mu scalar, [b] or [b,nx,ny]."""
     sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
-    sim.engine.check_info = check_info
     if eps_in is not None:
         sim.add_input_layer(eps=eps_in)
     if eps_out is not None:
@@ -75,7 +74,11 @@ def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtyp
 
 
 def _slice(v, lo, hi, B):
-    return v[lo:hi] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v
+    """Per-point quantities are [B] vectors or [B,nx,ny] grids; a 2-D tensor is a grid SHARED by all points and is never cut
+    (a 128 x 128 grid in a 128-point sweep is not a per-point quantity)."""
+    if torch.is_tensor(v) and v.dim() in (1, 3) and v.shape[0] == B:
+        return v[lo:hi]
+    return v
 
 
 def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0, dtype=torch.complex64,
@@ -84,8 +87,10 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
     """B sweep points of a multi-layer stack (BASELINE.json configs 2-4): the reference's per-point Python loop
     (example/Example1-1.ipynb, Example3.ipynb) as chunks of a batched solve.  `layers` as in `_solve_chunk`, with
     per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)]."""
-    import threading
+    from .engine import default_engine
     B = freq.shape[0]
+    eng = engine if engine is not None else default_engine()
+    old_check, eng.check_info = eng.check_info, check_info         # restored below: the engine may be shared with other solvers
     chunk = B if chunk is None else int(chunk)
     if streams > 1 and chunk >= B:
         chunk = -(-B // streams)
@@ -99,6 +104,15 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
                                _slice(azi_ang, lo, hi, B), dtype, precision, engine, orders, polarization, direction, port, check_info)
 
     dev = freq.device
+    try:
+        _run_spans(run, spans, streams, dev)
+    finally:
+        eng.check_info = old_check
+    return torch.cat(outs, dim=0)
+
+
+def _run_spans(run, spans, streams, dev):
+    import threading
     if streams <= 1 or len(spans) == 1 or dev.type != "cuda":
         for i in range(len(spans)):
             run(i)
@@ -125,7 +139,6 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
             raise errors[0]
         for st in pool:
             cur.wait_stream(st)
-    return torch.cat(outs, dim=0)
 
 
 def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):

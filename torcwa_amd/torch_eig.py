@@ -18,9 +18,17 @@ class Eig(torch.autograd.Function):
     def _eng():
         return Eig.engine if Eig.engine is not None else default_engine()
 
+    UNBROADENED = "unbroadened"
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, mode=None):
+        """mode None (the reference's signature, `Eig.apply(x)`): the backward reads `Eig.broadening_parameter` when it runs,
+        like torch_eig.py:27.  mode Eig.UNBROADENED: this call's backward never broadens, whatever the global says -- the
+        `stable_eig_grad=False` branch of the reference (rcwa.py:1238, plain torch.linalg.eig); the choice is bound to the
+        graph node at forward time, so no global is touched and concurrent solvers cannot disturb each other."""
         eng = Eig._eng()
+        ctx.mode = mode
+        ctx.nargs = 1 if mode is None else 2
         xb = x if x.dim() == 3 else x[None]
         was_real = not torch.is_complex(xb)
         if was_real:
@@ -40,11 +48,12 @@ class Eig(torch.autograd.Function):
         gw, gV = gw.to(w.dtype), gV.to(V.dtype)
         # F = conj(s)/(|s|^2 + eps), s_ij = w_j - w_i; eps = broadening, or the smallest positive number of the dtype when the
         # broadening is switched off (torch_eig.py:27-31); the whole adjoint is one libtrx call (include/trx.h: trx_eig_backward)
-        if Eig.broadening_parameter is not None:
+        if ctx.mode != Eig.UNBROADENED and Eig.broadening_parameter is not None:
             eps = float(Eig.broadening_parameter)
         else:
             eps = 1.4e-45 if w.dtype == torch.complex64 else 4.9e-324
         grad = eng.eig_backward(w, V, gw.contiguous(), gV.contiguous(), eps)
         if ctx.was_real:
             grad = torch.real(grad)
-        return grad if ctx.batched else grad[0]
+        grad = grad if ctx.batched else grad[0]
+        return grad if ctx.nargs == 1 else (grad, None)
