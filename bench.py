@@ -1,18 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- RCWA layer-solves/s on MI355X (BASELINE.json metric), one process per GPU.
 
-Workload (BASELINE.json configs[1]): single patterned layer (Example-1 rectangle 180x100 nm of a-Si:H on glass, 300 nm
+Default workload (BASELINE.json configs[1]): single patterned layer (Example-1 rectangle 180x100 nm of a-Si:H on glass, 300 nm
 thick, 300x300 grid), Fourier order [15,15] (n = 2N = 1922), wavelength sweep linspace(400,700,128) nm, complex64 I/O.
-A "step" = one pass of the hot path (conv-matrix -> P,Q -> eig -> layer S-matrix -> Redheffer with the input half
-space -> S-parameter read-out) over one batch of `--batch` sweep points whose permittivity grids are already resident
-in HBM.  N GPUs: every rank runs its own batch (weak scaling, no data-path collective); the only communication is
-the final all_gather of the S-parameters (RCCL).
+A "step" = one pass of the hot path (conv-matrix -> P,Q -> eig -> layer S-matrix -> Redheffer with the input half space ->
+S-parameter read-out) over one batch of sweep points whose permittivity grids are already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+    python bench.py                                  # 1 GPU, 128-lambda sweep, the driver's BENCH line
+    python bench.py --gpus 8                         # spawns 8 ranks itself (torch.distributed.run, RCCL); weak scaling: 128
+                                                     # points per GPU, PLUS the strong-scaling leg north_star asks for (the SAME
+                                                     # 128-lambda sweep split 8 ways) reported under "strong_scaling"
+    python bench.py --gpus 8 --scaling strong        # only the split sweep (value = its throughput)
+    python bench.py --gpus 8 --config 4              # configs[3]: 16x16x16 (Wx,Wy,lambda) sweep = 4096 solves, sharded (strong)
+
+Under `python -m torch.distributed.run ... bench.py --gpus N ...` (the driver's launch) the ranks are already there and nothing
+is spawned.  No data-path collective exists: every rank solves its own contiguous block of the flattened sweep
+(torcwa_amd.sweep.shard_range); the only communication is one all_gather of the S-parameters at the end.
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` (live HIP-event timing of the dominant kernels + the
+per-layer-solve T_roof/T_measured of SURVEY.md 8(d)) and, at N = 1, `cpu_baseline` (the oracle port of the reference's CPU
+path timed on the host cores).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,223 +37,394 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-
-def make_inputs(batch, order, device, rank, seed_shift=0):
-    from torcwa_amd.sweep import asih_eps_table, rectangle_density
-    lam, eps_si = asih_eps_table()
-    idx = (np.arange(batch) + rank * batch + seed_shift) % len(lam)
-    lam_b, eps_b = lam[idx], eps_si[idx]
-    dens = rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., dtype=torch.float32, device=device)
-    eps_t = torch.as_tensor(eps_b, dtype=torch.complex64, device=device)
-    grids = dens[None] * eps_t[:, None, None] + (1. - dens[None])            # complex64 [B,300,300], as a c64 user builds it
-    freq = torch.as_tensor(1.0 / lam_b, dtype=torch.float64, device=device)
-    return freq, grids.contiguous(), lam_b
-
-
-def run_step(freq, grids, order, engine, precision, chunk, streams):
-    from torcwa_amd.sweep import solve_single_layer_sweep
-    return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
-                                    precision=precision, engine=engine, chunk=chunk, streams=streams, check_info=False)
-
-
-def cpu_baseline(order, lam_nm, eps_si, threads):
-    """The reference's CPU path (oracle port, same op sequence), timed on the host cores on a bounded sample:
-    one layer-solve in complex64 (the timed baseline, as the reference runs it) and the same point in complex128
-    (the parity oracle, SURVEY.md section 8c)."""
-    from oracle import rcwa_oracle as orc
-    torch.set_num_threads(threads)
-    dens = orc.rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., dtype=torch.float32)
-    eps = (dens * complex(eps_si) + (1. - dens)).to(torch.complex64)
-    t0 = time.perf_counter()
-    s, lays, S, C = orc.solve_stack(1.0 / float(lam_nm), order, [300., 300.], [(300., eps, 1.0)], dtype=torch.complex64, eps_in=1.46 ** 2)
-    v = orc.s_parameters(s, S, [0, 0])
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    s, lays, S, C = orc.solve_stack(1.0 / float(lam_nm), order, [300., 300.], [(300., eps.to(torch.complex128), 1.0)], dtype=torch.complex128, eps_in=1.46 ** 2)
-    v128 = orc.s_parameters(s, S, [0, 0])
-    dt128 = time.perf_counter() - t1
-    return dt, complex(v[0]), dt128, complex(v128[0])
-
-
-# MI355X dense matrix-core peaks for the arithmetic type of the path.  f32: 157.3 TF (MI355X_MICROARCH.md, "Peak FP32
-# (matrix)"); f64: 78.6 TF (AMD MI355X datasheet; the guide only states that the f32 matrix rate equals the vector rate
-# and f64 runs at half of it).  HBM3E: 8 TB/s spec.
+# MI355X dense matrix-core peaks for the arithmetic type of the path.  f32: 157.3 TF (MI355X_MICROARCH.md, "Peak FP32 (matrix)");
+# f64: 78.6 TF (AMD MI355X datasheet; a register-only MFMA loop sustains 77.5 TF, profiles/r01_mfma_peak.txt).  HBM3E: 8 TB/s.
 PEAK_TFLOPS = {"high": 78.6, "native": 157.3}
 PEAK_HBM_GBS = 8000.0
+EMU = os.environ.get("TRX_BENCH_EMU") == "1"       # launcher-plumbing test on CPU (tests/test_bench_launch.py); never a measurement
 
 
-def roofline(engine, precision, elapsed, batch_per_gpu=None):
-    """Live figures from the HIP events libtrx recorded around its dominant kernels during the timed region."""
-    import ctypes
-    tags = []
-    for tag in range(6):
-        buf = (ctypes.c_double * 6)()
-        engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
-        launches, timed, flops, nbytes, ms, flops_all = list(buf)
-        tags.append({"kernel": engine.lib.prof_tag_name(tag).decode(), "launches": int(launches), "timed_launches": int(timed),
-                     "ms_timed": ms, "flops_timed": flops, "bytes_timed": nbytes, "flops_all": flops_all})
-    times = [{"kernel": t["kernel"], "launches": t["launches"], "timed_launches": t["timed_launches"],
-              "avg_us": (1e3 * t["ms_timed"] / t["timed_launches"]) if t["timed_launches"] else None,
-              "share_of_wall": (t["ms_timed"] * (t["launches"] / max(t["timed_launches"], 1)) / (1e3 * elapsed)) if t["timed_launches"] else None}
-             for t in tags]
-    # dominant kernel with a known algorithmic work figure: the N,N complex GEMM on the matrix cores
-    g = tags[0]
-    roof = None
-    if g["timed_launches"] > 0 and g["ms_timed"] > 0:
-        ach = g["flops_timed"] / (g["ms_timed"] * 1e-3) / 1e12
-        roof = {"kernel": g["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                "frac": ach / PEAK_TFLOPS[precision], "traffic": None,
-                "avg_launch_us": 1e3 * g["ms_timed"] / g["timed_launches"], "launches_timed": g["timed_launches"],
-                "algorithmic_flops_per_launch": g["flops_timed"] / g["timed_launches"],
-                "algorithmic_bytes_per_launch": g["bytes_timed"] / g["timed_launches"],
-                "note": "8 real flops per complex MAC x m*n*k*batch of each launch; events on the launch stream"}
-        h = tags[5]
-        if h["timed_launches"] > 0 and h["ms_timed"] > 0:
-            gbs = h["bytes_timed"] / (h["ms_timed"] * 1e-3) / 1e9
-            roof["secondary"] = {"kernel": h["kernel"], "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * h["ms_timed"] / h["timed_launches"]}
-        a = tags[3]    # QR slab updates: the work is data dependent and counted on the device (all launches); time = avg of the timed launches
-        if a["timed_launches"] > 0 and a["ms_timed"] > 0 and a["flops_all"] > 0:
-            tf = a["flops_all"] / (a["ms_timed"] * 1e-3 * a["launches"] / a["timed_launches"]) / 1e12
-            roof["qr_slab_updates"] = {"kernel": a["kernel"], "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                                       "frac": tf / PEAK_TFLOPS[precision], "avg_launch_us": 1e3 * a["ms_timed"] / a["timed_launches"],
-                                       "note": "flops = 8 ww^2 (2n - ww) per matrix and window step, summed on the device over all launches; up to 4 iteration "
-                                               "groups run this kernel concurrently on their own streams, so the event-bracketed time of a launch includes "
-                                               "the share of the GPU the other groups take: this is the rate ONE group sees, the aggregate is up to 4x"}
-    # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot be
-    # collected from inside this process).  Only reported when the committed summary was taken at this batch size.
-    if roof is not None:
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
-        try:
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-            if pmc.get("batch") == batch_per_gpu:
-                kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("gemm_mfma_kernel<double, 0, 0" if precision == "high" else "gemm_mfma_kernel<float, 0, 0")]
-                if kk:
-                    tot = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk)
-                    n_l = sum(v["launches"] for v in kk)
-                    roof["traffic"] = tot / n_l
-                    roof["traffic_note"] = ("HBM bytes per launch, average over the launches of this kernel in one step: 2*FETCH_SIZE + WRITE_SIZE from "
-                                            "profiles/r01_pmc_bench.json (separate --pmc passes of the same command)")
-        except (OSError, ValueError, KeyError):
-            pass
-    return roof, times
-
-
-def main():
+# ---------------------------------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="sweep points per step per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4], help="BASELINE.json config: 2 = lambda sweep (configs[1]), 4 = (Wx,Wy,lambda) sweep (configs[3])")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: weak for config 2, strong for config 4")
+    ap.add_argument("--batch", type=int, default=128, help="config 2: sweep points per GPU (weak) / in total (strong)")
+    ap.add_argument("--points", type=int, default=4096, help="config 4: total sweep points (16^3 grid, cycled if larger)")
     ap.add_argument("--order", type=int, default=15)
-    ap.add_argument("--chunk", type=int, default=0, help="points solved concurrently (0 = whole batch)")
+    ap.add_argument("--grid", type=int, default=300, help="permittivity grid is grid x grid")
+    ap.add_argument("--chunk", type=int, default=0, help="points solved in lock-step (0 = min(local points, 128))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-profile", action="store_true", help="cProfile of one extra (untimed) step, top entries to stderr")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
+    ap.add_argument("--cpu-points", type=int, default=3, help="sweep points the CPU baseline times (>= 1)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of one extra (untimed) step, top entries to stderr")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: re-execute this script under torch.distributed.run with N ranks (one per
+    GPU; rendezvous on 127.0.0.1) and pass its exit code on.  Rank 0 of that job prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# workloads: sweep point g (global index) -> (frequency, permittivity grid)
+# ---------------------------------------------------------------------------------------------------------------------------
+def make_inputs(config, idx, grid, device):
+    """Inputs of the sweep points with global indices `idx` (numpy int array), built on `device` (resident before the timed
+    region).  config 2: fixed rectangle 180 x 100, lambda_g = linspace(400,700,128)[g mod 128].  config 4: g -> (iw, jw, kl) of
+    the 16^3 grid Wx, Wy in linspace(50,250,16), lambda in linspace(400,700,16) (example/Example3.ipynb:85-101 at BASELINE size)."""
+    from torcwa_amd.geometry import geometry
+    from torcwa_amd.materials import asih_nk
+    from torcwa_amd.sweep import asih_eps_table
+    geo = geometry(Lx=300., Ly=300., nx=grid, ny=grid, edge_sharpness=1000., dtype=torch.float32, device=device)
+    if config == 2:
+        lam_t, eps_t = asih_eps_table()
+        k = idx % len(lam_t)
+        lam, eps_si = lam_t[k], eps_t[k]
+        dens = geo.rectangle(Wx=180., Wy=100., Cx=150., Cy=150.)[None]
+    else:
+        iw, jw, kl = np.unravel_index(idx % 4096, (16, 16, 16))
+        wv = np.linspace(50., 250., 16)
+        lam = np.linspace(400., 700., 16)[kl]
+        eps_si = (asih_nk(torch.from_numpy(lam)) ** 2).numpy()
+        wx = torch.as_tensor(wv[iw], dtype=torch.float32, device=device)[:, None, None]
+        wy = torch.as_tensor(wv[jw], dtype=torch.float32, device=device)[:, None, None]
+        dens = geo.rectangle(Wx=wx, Wy=wy, Cx=150., Cy=150.)
+    eps_c = torch.as_tensor(eps_si, dtype=torch.complex64, device=device)
+    grids = dens * eps_c[:, None, None] + (1. - dens)                      # complex64 [B,grid,grid], as a complex64 user builds it
+    freq = torch.as_tensor(1.0 / lam, dtype=torch.float64, device=device)
+    return freq, grids.contiguous(), lam, eps_si
+
+
+def run_step(freq, grids, order, engine, args, chunk):
+    from torcwa_amd.sweep import solve_single_layer_sweep
+    return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
+                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle port of the reference, test infrastructure -- only this leg imports it)
+# ---------------------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) if cores else max(1, logical // 2)), logical
+
+
+def cpu_baseline(order, grid, lams, eps_sis, threads):
+    """The reference's CPU path (oracle/rcwa_oracle.py: same op sequence -- 1 eig / 12 inv / 48 matmul per layer-solve), timed
+    on the host cores on a BOUNDED sample: len(lams) sweep points of the same workload in complex64 with denormals NOT flushed
+    (as the reference runs), one of them again with flush-to-zero (footnote), and the first point in complex128
+    (the parity oracle, SURVEY.md 8c)."""
+    from oracle import rcwa_oracle as orc
+    torch.set_num_threads(threads)
+    dens = orc.rectangle_density(grid, grid, 300., 300., 180., 100., 150., 150., dtype=torch.float32)
+
+    def solve(lam, eps_si, cdt):
+        eps = (dens * torch.tensor(complex(eps_si), dtype=torch.complex64) + (1. - dens)).to(torch.complex64).to(cdt)
+        t0 = time.perf_counter()
+        s, lays, S, C = orc.solve_stack(1.0 / float(lam), order, [300., 300.], [(300., eps, 1.0)], dtype=cdt, eps_in=1.46 ** 2)
+        v = complex(orc.s_parameters(s, S, [0, 0])[0])
+        return time.perf_counter() - t0, v
+
+    secs, vals = [], []
+    for lam, e in zip(lams, eps_sis):
+        dt, v = solve(lam, e, torch.complex64)
+        secs.append(dt)
+        vals.append(v)
+    torch.set_flush_denormal(True)
+    dt_flush, _ = solve(lams[0], eps_sis[0], torch.complex64)
+    torch.set_flush_denormal(False)
+    dt128, v128 = solve(lams[0], eps_sis[0], torch.complex128)
+    return secs, vals, dt_flush, dt128, v128
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# roofline
+# ---------------------------------------------------------------------------------------------------------------------------
+def csrc_sha16():
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "torcwa_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "torcwa_amd", "csrc", "*.hpp"))):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def layer_solve_roof(n, precision):
+    """nominal work of one patterned layer-solve, F_dense = 160 n^3, F_eig = 100 n^3 real flops, B_eig,min =
+    elem * n^3 / 3 bytes; T_roof = F_dense / P + max(F_eig / P, B_eig,min / 8 TB/s)."""
+    n3 = float(n) ** 3
+    out = {}
+    for key, peak, elem in (("survey_fp32", 157.3e12, 8), ("fp64", 78.6e12, 16)):
+        out[key] = 1e3 * (160 * n3 / peak + max(100 * n3 / peak, elem * n3 / 3 / 8e12))
+    return out
+
+
+_BOUND = {"gemm_mfma_kernel<N,N>": "mfma", "gemm_mfma_kernel<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm"}
+
+
+def roofline(engine, args, elapsed, steps, n, units_per_step):
+    """Live figures from the HIP events libtrx recorded (on the launch streams, uniformly sampled) during the timed region."""
+    import ctypes
+    peak_tf = PEAK_TFLOPS[args.precision]
+    kernels = []
+    for tag in range(8):
+        buf = (ctypes.c_double * 6)()
+        engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
+        launches, timed, flops_t, bytes_t, ms, flops_all = list(buf)
+        if timed <= 0 or ms <= 0:          # not launched, or no usable event timing (CPU emulator)
+            continue
+        name = engine.lib.prof_tag_name(tag).decode()
+        avg_us = 1e3 * ms / timed
+        k = {"kernel": name, "launches": int(launches), "timed_launches": int(timed), "avg_us": avg_us,
+             "est_total_ms_per_step": avg_us * launches / 1e3 / steps, "sum_over_wall": avg_us * launches / 1e6 / elapsed}
+        bound = _BOUND.get(name)
+        if name == "apply_window_kernel" and flops_all > 0:
+            # data-dependent work, counted on the device over ALL launches; time = uniform-sample average x launches
+            k.update(bound="mfma", achieved=flops_all / (avg_us * 1e-6 * launches) / 1e12, peak=peak_tf, unit="TFLOP/s",
+                     algorithmic_flops_per_launch=flops_all / launches,
+                     note="flops = 8 ww^2 (2n - ww) per matrix and window step; the iteration groups of the QR phase run this kernel "
+                          "concurrently on their own streams, so a launch's event time includes the share of the GPU the others take")
+        elif bound == "mfma" and flops_t > 0:
+            k.update(bound="mfma", achieved=flops_t / (ms * 1e-3) / 1e12, peak=peak_tf, unit="TFLOP/s",
+                     algorithmic_flops_per_launch=flops_t / timed, algorithmic_bytes_per_launch=bytes_t / timed)
+        elif bound == "hbm" and bytes_t > 0:
+            k.update(bound="hbm", achieved=bytes_t / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_launch=bytes_t / timed)
+        else:
+            # one wave / one workgroup per matrix, dependent chain of small steps: no meaningful flop or byte rate
+            k.update(bound="hbm", achieved=0.0, peak=PEAK_HBM_GBS, unit="GB/s", note="latency-bound (one wave or workgroup per matrix)")
+        k["frac"] = k["achieved"] / k["peak"]
+        kernels.append(k)
+    kernels.sort(key=lambda k: -k["est_total_ms_per_step"])
+    if not kernels:
+        return None
+    dom = dict(kernels[0])
+    dom["chosen_by"] = "largest summed event time (uniform-sample average x launches) among the instrumented kernels"
+    dom["traffic"], dom["traffic_note"] = pmc_traffic(dom["kernel"], args)
+    t_meas = 1e3 * elapsed / (steps * units_per_step)
+    roofs = layer_solve_roof(n, args.precision)
+    dom["layer_solve"] = {
+        "t_measured_ms": t_meas, "definition": "SURVEY.md 8(d): T_roof / T_measured per patterned layer-solve, nominal 260 n^3 flops + n^3/3 element reads",
+        "t_roof_ms_at_fp32_peak": roofs["survey_fp32"], "frac_at_fp32_peak": roofs["survey_fp32"] / t_meas,
+        "t_roof_ms_at_fp64_peak": roofs["fp64"], "frac_at_fp64_peak": roofs["fp64"] / t_meas,
+        "priced_at": "fp64 (78.6 TF, 16-byte elements): the path computes in complex128 (DESIGN.md section 3); the survey's own figure "
+                     "prices the same flops at the fp32 peak" if args.precision == "high" else "fp32 (157.3 TF, 8-byte elements)"}
+    dom["kernels"] = kernels
+    return dom
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot
+    be collected from inside this process).  Accepted only when the summary was taken on the SAME kernel sources (hash of
+    torcwa_amd/csrc) and at this batch size -- otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+    try:
+        pmc = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no PMC summary committed for this round"
+    if pmc.get("csrc_sha16") != csrc_sha16():
+        return None, "profiles/r02_pmc_bench.json was taken on other kernel sources (csrc hash %s != %s): refused" % (pmc.get("csrc_sha16"), csrc_sha16())
+    if pmc.get("batch") != args.batch or args.config != 2:
+        return None, "profiles/r02_pmc_bench.json was taken at another workload"
+    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float")}.get(kernel, kernel.split("<")[0])
+    kk = [v for k_, v in pmc.get("kernels", {}).items() if k_.startswith(key)]
+    if not kk:
+        return None, "kernel not in the PMC summary"
+    tot = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk)
+    return tot / sum(v["launches"] for v in kk), ("HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of the same command, "
+                                                  "same kernel sources): profiles/r02_pmc_bench.json")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
-
     import torcwa_amd
-    from torcwa_amd.sweep import gather_sweep
-    engine = torcwa_amd.Engine(device=device)
+    from torcwa_amd.sweep import gather_sweep, shard_range
+    if EMU:
+        from tests.emu import emu_lib
+        device = torch.device("cpu")
+        engine = torcwa_amd.Engine(lib=emu_lib(), device="cpu")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=device)        # "nccl" is RCCL on ROCm
+        engine = torcwa_amd.Engine(device=device)
+    world = dist.get_world_size() if world > 1 else 1                          # the world size RCCL actually formed
+
+    scaling = args.scaling or ("weak" if args.config == 2 else "strong")
     order = [args.order, args.order]
     n = 2 * (2 * args.order + 1) ** 2
-    chunk = args.chunk if args.chunk > 0 else -(-args.batch // max(1, args.streams))
-    freq, grids, lam_b = make_inputs(args.batch, order, device, rank)
+
+    def sync():
+        if not EMU:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    for w in range(args.warmup):
-        try:
-            out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
-        except (RuntimeError, torcwa_amd.TrxError) as e:
-            # an untimed warm-up step may hit a device that is still releasing the memory of a previous process: free the
-            # allocator cache, wait and try once more (the timed steps below are never retried)
-            if w > 0:
-                raise
-            print("bench: warm-up step failed (%s); retrying once" % str(e).splitlines()[0], file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
-            time.sleep(10.0)
-            out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
-    barrier()
-    # HIP-event timing of the dominant kernels, recorded by libtrx on the launch stream during the timed region
-    engine.lib.prof_reset()
-    engine.lib.prof_enable(1)
-    ms0 = torch.cuda.memory_stats(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    engine.lib.prof_enable(0)
-    ms1 = torch.cuda.memory_stats(device)
-    mem = {"peak_reserved_GB": ms1.get("reserved_bytes.all.peak", 0) / 1e9, "peak_allocated_GB": ms1.get("allocated_bytes.all.peak", 0) / 1e9,
-           "device_mallocs_in_timed_region": ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0),
-           "device_frees_in_timed_region": ms1.get("segment.all.freed", 0) - ms0.get("segment.all.freed", 0),
-           "alloc_retries": ms1.get("num_alloc_retries", 0)}
+    def local_block(total):
+        lo, hi = shard_range(total, rank, world)
+        return np.arange(lo, hi)
+
+    def measure(idx, steps, warmup, profile):
+        """W untimed + K timed steps over this rank's sweep points `idx`; returns (elapsed max over ranks, last result, inputs)."""
+        freq, grids, lam, eps_si = make_inputs(args.config, idx, args.grid, device)
+        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), 128))
+        out = None
+        for w in range(warmup):
+            try:
+                out = run_step(freq, grids, order, engine, args, chunk)
+            except (RuntimeError, torcwa_amd.TrxError) as e:
+                # an untimed warm-up step may hit a device that is still releasing the memory of a previous process: free the
+                # allocator cache, wait and try once more (the timed steps below are never retried)
+                if w > 0:
+                    raise
+                print("bench: warm-up step failed (%s); retrying once" % str(e).splitlines()[0], file=sys.stderr, flush=True)
+                sync()
+                if not EMU:
+                    torch.cuda.empty_cache()
+                time.sleep(10.0)
+                out = run_step(freq, grids, order, engine, args, chunk)
+        barrier()
+        if profile:
+            engine.lib.prof_reset()
+            engine.lib.prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = run_step(freq, grids, order, engine, args, chunk)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        engine.lib.prof_enable(0)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed, out, (freq, grids, lam, eps_si, chunk)
+
+    # ---- primary measurement ------------------------------------------------------------------------------------------
+    if args.config == 2:
+        total = args.batch * world if scaling == "weak" else args.batch
+        idx = np.arange(rank * args.batch, (rank + 1) * args.batch) if scaling == "weak" else local_block(total)
+    else:
+        total = args.points
+        idx = local_block(total)
+        if scaling == "weak":
+            total, idx = args.points * world, np.arange(rank * args.points, (rank + 1) * args.points)
+    ms0 = torch.cuda.memory_stats(device) if not EMU else {}
+    elapsed, out, (freq, grids, lam, eps_si, chunk) = measure(idx, args.steps, args.warmup, profile=True)
+    ms1 = torch.cuda.memory_stats(device) if not EMU else {}
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
+    roof = roofline(engine, args, elapsed, args.steps, n, len(idx)) if rank == 0 else None
     if args.host_profile and rank == 0:
-        import cProfile, pstats, sys
+        import cProfile
+        import pstats
         pr = cProfile.Profile()
         pr.enable()
-        run_step(freq, grids, order, engine, args.precision, chunk, args.streams)
-        torch.cuda.synchronize()
+        run_step(freq, grids, order, engine, args, chunk)
+        sync()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        full = gather_sweep(out, args.batch * world)       # the one collective of the job: final gather (RCCL)
-    else:
-        full = out
-    total_solves = args.batch * world * args.steps
-    value = total_solves / elapsed
+    full = gather_sweep(out, total) if world > 1 else out                 # the one collective of the job (RCCL all_gather, KB-sized)
+    value = total * args.steps / elapsed
+
+    # ---- strong-scaling leg (north_star: ">= 6x strong scaling of a wavelength sweep at 8 GPUs") ------------------------------
+    strong = None
+    if world > 1 and scaling == "weak" and args.config == 2 and not args.no_strong_leg:
+        sidx = local_block(args.batch)
+        el_s, out_s, _ = measure(sidx, args.steps, 1, profile=False)
+        full_s = gather_sweep(out_s, args.batch)
+        n_fail = engine.failures()
+        strong = {"workload": "the SAME %d-lambda sweep split over %d GPUs (%d-%d points per GPU)" % (args.batch, world, args.batch // world, -(-args.batch // world)),
+                  "value": args.batch * args.steps / el_s, "unit": "layer-solves/s", "ms_per_step": 1e3 * el_s / args.steps, "steps": args.steps,
+                  "gathered_points": int(full_s.shape[0]), "numerical_failures": int(n_fail),
+                  "speedup": "value / (value of the n_gpus = 1 run of this script: same sweep on one GPU)"}
 
     if rank == 0:
+        mem = None
+        if not EMU:
+            mem = {"peak_reserved_GB": ms1.get("reserved_bytes.all.peak", 0) / 1e9, "peak_allocated_GB": ms1.get("allocated_bytes.all.peak", 0) / 1e9,
+                   "device_mallocs_in_run": ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0), "alloc_retries": ms1.get("num_alloc_retries", 0)}
+        wl = ("configs[1]: single patterned layer, order=[%d,%d] (n=%d), %dx%d grid, %d-lambda sweep, glass input half-space"
+              % (args.order, args.order, n, args.grid, args.grid, args.batch)) if args.config == 2 else \
+             ("configs[3]: Example3-style (Wx,Wy,lambda) sweep, %d independent single-layer solves, order=[%d,%d] (n=%d), %dx%d grid, sharded by contiguous blocks"
+              % (total, args.order, args.order, n, args.grid, args.grid))
         res = {
             "metric": "RCWA layer-solves/sec (complex64 I/O) at Fourier order [%d,%d]" % (args.order, args.order),
             "value": value, "unit": "layer-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "c128 arithmetic (complex64 I/O)" if args.precision == "high" else "c64",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: single patterned layer, order=[%d,%d] (n=%d), 300x300 grid, %d-lambda sweep per GPU, "
-                                   "glass input half-space" % (args.order, args.order, n, args.batch),
-                       "batch_per_gpu": args.batch, "chunk": chunk, "streams": args.streams, "precision": args.precision},
-            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "numerical_failures": 0, "hbm": mem,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "c128 arithmetic (fp64 MFMA; complex64 I/O)" if args.precision == "high" else "c64",
+            "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
+            "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "chunk": int(chunk), "streams": args.streams,
+                       "precision": args.precision, "backend": ("gloo" if EMU else "nccl (RCCL)") if world > 1 else None},
+            "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "gathered_points": int(full.shape[0]),
+            "numerical_failures": 0, "hbm": mem, "csrc_sha16": csrc_sha16(),
         }
-        res["roofline"], res["kernel_times"] = roofline(engine, args.precision, elapsed, args.batch)
-        if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads if args.cpu_threads > 0 else max(1, (os.cpu_count() or 2) // 2)
-            from torcwa_amd.sweep import asih_eps_table
-            lam, eps_si = asih_eps_table()
-            dt, v, dt128, v128 = cpu_baseline(order, lam[0], eps_si[0], threads)
-            got = complex(full[0, 0])
-            res["parity_sample"] = {"point": "lambda=%.1f nm, txx(0,0)" % lam[0], "gpu": [got.real, got.imag],
+        if strong is not None:
+            res["strong_scaling"] = strong
+        res["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:
+            model, phys, logical = host_cpu()
+            threads = args.cpu_threads if args.cpu_threads > 0 else phys
+            npts = max(1, min(args.cpu_points, len(lam)))
+            pick = sorted(set(int(round(i * (len(lam) - 1) / max(npts - 1, 1))) for i in range(npts)))
+            secs, vals, dt_flush, dt128, v128 = cpu_baseline(order, args.grid, [lam[i] for i in pick], [eps_si[i] for i in pick], threads)
+            got = complex(full[pick[0], 0])
+            res["parity_sample"] = {"point": "lambda=%.1f nm, txx(0,0)" % lam[pick[0]], "gpu": [got.real, got.imag],
                                     "oracle_c128": [v128.real, v128.imag], "rel_err_vs_c128_oracle": abs(got - v128) / abs(v128),
-                                    "oracle_c64": [v.real, v.imag], "rel_err_of_c64_oracle_vs_c128_oracle": abs(v - v128) / abs(v128),
+                                    "oracle_c64": [vals[0].real, vals[0].imag], "rel_err_of_c64_oracle_vs_c128_oracle": abs(vals[0] - v128) / abs(v128),
                                     "oracle_c128_seconds": dt128}
-            res["cpu_baseline"] = {"value": 1.0 / dt, "unit": "layer-solves/s", "cores": threads, "kind": "port",
-                                   "sample": "1 layer-solve (lambda=%.1f nm) of the same workload, complex64, oracle/rcwa_oracle.py on torch-CPU; "
-                                             "txx00=%.6f%+.6fj" % (lam[0], v.real, v.imag)}
+            res["cpu_baseline"] = {"value": len(secs) / sum(secs), "unit": "layer-solves/s", "cores": threads, "kind": "port",
+                                   "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+                                   "seconds_per_layer_solve": secs, "flush_denormal_seconds_footnote": dt_flush,
+                                   "sample": "%d layer-solves of the same workload (lambda = %s nm), complex64, denormals not flushed (as the reference "
+                                             "runs), oracle/rcwa_oracle.py on torch-CPU with %d threads = physical cores; footnote: the first point "
+                                             "again with torch.set_flush_denormal(True)" % (len(secs), ", ".join("%.1f" % lam[i] for i in pick), threads)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

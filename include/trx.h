@@ -135,11 +135,12 @@ int trx_build_a(int dtype, const void* E, const void* Einv, const void* mu, cons
                 void* ws, size_t ws_bytes, void* stream);
 
 /* ---- measurement aid (no reference counterpart): HIP-event timing of the dominant kernels --------------------
- * trx_prof_enable(1) makes the instrumented launch sites record hipEvents on the launch stream (pool of 4096 per
- * tag; launches beyond the pool are counted but not timed).  trx_prof_get(tag, out[6]) waits for those events and
- * returns {launches, timed_launches, algorithmic flops of the timed launches, algorithmic bytes of the timed
- * launches, milliseconds of the timed launches, flops of all launches}.  Tags: 0 gemm N,N; 1 gemm other ops;
- * 2 QR apply_left; 3 QR apply_right; 4 QR window; 5 Hessenberg gemv. */
+ * trx_prof_enable(1) makes the instrumented launch sites record hipEvents on the launch stream.  Sampling is systematic and
+ * uniform over the run: every stride-th launch of a tag is timed; when the pool (2048 event pairs per tag) is full every
+ * other sample is dropped and the stride doubles.  trx_prof_get(tag, out[6]) waits for those events and returns
+ * {launches, timed_launches, algorithmic flops of the timed launches, algorithmic bytes of the timed launches,
+ * milliseconds of the timed launches, flops of all launches}.  Tags: 0 gemm N,N; 1 gemm other ops; 2 QR prepare (AED);
+ * 3 QR off-window update; 4 QR window chase; 5 Hessenberg gemv; 6 Hessenberg reflector column; 7 LU panel. */
 int trx_prof_enable(int on);
 int trx_prof_reset(void);
 int trx_prof_get(int tag, double* out);

@@ -11,8 +11,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcb_$c -o g -- python $GRAFT_REPO_ROOT/bench.py --batch $B --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 done
 python - "$B" "$OUT" <<'PYEOF'
-import sqlite3, glob, re, json, sys
+import sqlite3, glob, re, json, sys, os
 batch, out = int(sys.argv[1]), sys.argv[2]
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from bench import csrc_sha16          # hash of torcwa_amd/csrc: bench.py accepts this summary only on the same kernel sources
 def short(name):
     m = re.search(r"([A-Za-z_0-9]+)<([^>(]*)", name)
     return f"{m.group(1)}<{m.group(2)}>" if (m and "trx" in name) else re.sub(r"\(.*", "", name)[:40]
@@ -26,9 +28,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if c == "FETCH_SIZE": a["n"] += 1
 print(f"# bench.py --batch {batch} --steps 1 --warmup 0, one rocprofv3 --pmc pass per counter")
 print(f"{'kernel':44s} {'calls':>7s} {'ms':>9s} {'FETCH_GB(raw)':>14s} {'WRITE_GB':>10s} {'(F+W)/t GB/s':>13s} {'(2F+W)/t GB/s':>14s} {'MB/launch(2F+W)':>16s}")
-js = {"batch": batch, "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --batch %d --steps 1 --warmup 0 --no-cpu-baseline" % batch,
+js = {"batch": batch, "csrc_sha16": csrc_sha16(), "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --batch %d --steps 1 --warmup 0 --no-cpu-baseline" % batch,
       "note": "KB counters summed over all launches of a kernel; corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE under-reports coalesced reads 2x)", "kernels": {}}
-for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["dur_FETCH_SIZE"])[:14]:
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["dur_FETCH_SIZE"])[:16]:
     t = a["dur_FETCH_SIZE"] * 1e-9
     f, w = a["FETCH_SIZE"] * 1024 / 1e9, a["WRITE_SIZE"] * 1024 / 1e9
     print(f"{k:44s} {a['n']:7d} {t*1e3:9.1f} {f:14.1f} {w:10.1f} {(f+w)/t:13.0f} {(2*f+w)/t:14.0f} {(2*f+w)*1e3/max(a['n'],1):16.1f}")

@@ -13,9 +13,9 @@ _emu = None
 def emu_lib():
     global _emu
     if _emu is None:
-        from torcwa_amd.csrc import build
+        from tests.hipemu.build_emu import build_emu
         from torcwa_amd._lib import TrxLib
-        _emu = TrxLib(build.build_emu())
+        _emu = TrxLib(build_emu())
     return _emu
 
 

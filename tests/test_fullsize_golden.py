@@ -54,7 +54,7 @@ def test_config4_batched_geometry_sweep(dtype, tol):
     cdt = torch.complex128 if dtype == "c128" else torch.complex64
     grids = torch.stack([torch.from_numpy(g["L0_eps_grid"]).to(cdt) for g in gs]).to(eng.device)
     freq = torch.tensor([float(g["freq"]) for g in gs], dtype=torch.float64, device=eng.device)
-    for pol, b in (("xx", 0), ("yy", 3), ("ps", 6)):
+    for pol, b in (("xx", 0), ("yy", 3), ("pp", 4)):
         for chunk in ((8, 3) if pol == "xx" else (8,)):        # ragged chunks: 3 + 3 + 2
             got = solve_stack_sweep(freq, [(300., grids)], [15, 15], [300., 300.], eps_in=1.46 ** 2, dtype=cdt, engine=eng, chunk=chunk,
                                     orders=[tuple(o) for o in ORDERS_PROBE[:7]], polarization=pol).cpu().numpy()

@@ -103,7 +103,9 @@ def check_against_golden(sim, g, dtype, tol, avoid=False):
     for a, (dr, pt) in enumerate(DIRPORT):
         for b, pol in enumerate(POLS):
             v = sim.S_parameters(orders=ORDERS_PROBE, direction=dr, port=pt, polarization=pol, ref_order=[0, 0]).cpu().numpy()
-            scale = max(np.abs(sp[a, b]).max(), 1e-3)
+            # relative to the largest S-parameter of this (direction, port): polarisation pairs that vanish by symmetry (yx, xy,
+            # sp, ps of a mirror-symmetric meta-atom) are rounding noise of size eps * cond in BOTH implementations
+            scale = max(np.abs(sp[a]).max(), 1e-3)
             assert np.abs(v - sp[a, b]).max() / scale < tol, (dr, pt, pol)
     v = sim.S_parameters(orders=ORDERS_PROBE, direction="f", port="t", polarization="yx", ref_order=[-1, 1], power_norm=False).cpu().numpy()
     assert np.abs(v - g["sparams_yx_ref_m1p1_nonorm"]).max() < tol

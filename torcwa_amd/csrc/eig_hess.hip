@@ -231,7 +231,8 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
         const int r0 = p0 + 1, nr = n - r0;
         if (hipMemsetAsync(Tm, 0, sizeof(cx<T>) * sT * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
         for (int c = 0; c <= ib; ++c) {
-            TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau);
+            { ProfScope prof(PROF_HESS_COL, s, 0, 0);
+              TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau); }
             if (c < ib) {
                 const int j = p0 + c;
                 const int rpb = 64;

@@ -9,6 +9,7 @@
 //   trsm_lower_kernel    U12 = L11^-1 A12      (one thread per column, L11 broadcast from LDS)
 //   gemm                 A22 -= L21 U12
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace trx {
 namespace {
@@ -204,7 +205,8 @@ int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int ba
         const int Kend = K0 + kb;
         for (int c0 = K0; c0 < Kend; c0 += NB) {
             const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-            TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
+            { ProfScope prof(PROF_LU_PANEL, s, 0, 0);
+              TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info); }
             if (n - jb > 0)
                 TRX_LAUNCH((lu_swap_kernel<T>), dim3(cdiv_i(n - jb, 256), batch), dim3(256), 0, s, A, lda, sA, n, c0, jb, (const int*)piv, n);
             const int wcols = Kend - (c0 + jb);       // columns of the outer block still to be factored

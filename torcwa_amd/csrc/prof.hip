@@ -5,17 +5,18 @@
 
 namespace trx {
 namespace {
+constexpr int POOL = 2048;
 struct TagData {
     std::vector<hipEvent_t> start, stop;
-    int used = 0;          // event pairs recorded
-    double launches = 0;   // all launches seen while enabled (also those beyond the pool)
+    std::vector<double> sflops, sbytes;       // algorithmic work of each sampled launch
+    int used = 0;          // event pairs in use
+    long stride = 1;       // every stride-th launch is sampled
+    double launches = 0;   // all launches seen while enabled
     double flops = 0, bytes = 0;           // summed over ALL launches
-    double flops_timed = 0, bytes_timed = 0;   // summed over the timed (event-bracketed) launches
 };
 TagData g_tags[PROF_NTAGS];
 bool g_on = false;
 std::mutex g_mu;
-constexpr int POOL = 4096;
 }  // namespace
 
 bool prof_enabled() { return g_on; }
@@ -23,19 +24,34 @@ bool prof_enabled() { return g_on; }
 int prof_begin(int tag, hipStream_t s, double flops, double bytes) {
     std::lock_guard<std::mutex> lock(g_mu);
     TagData& t = g_tags[tag];
+    const long idx = (long)t.launches;
     t.launches += 1;
     t.flops += flops;
     t.bytes += bytes;
-    if (t.used >= POOL) return -1;
+    if (idx % t.stride != 0) return -1;
+    if (t.used >= POOL) {
+        // pool full: keep the samples of the even multiples of the stride (slots 0, 2, 4, ...), double the stride
+        for (int i = 0; 2 * i < t.used; ++i) {
+            std::swap(t.start[i], t.start[2 * i]);
+            std::swap(t.stop[i], t.stop[2 * i]);
+            t.sflops[i] = t.sflops[2 * i];
+            t.sbytes[i] = t.sbytes[2 * i];
+        }
+        t.used = (t.used + 1) / 2;
+        t.stride *= 2;
+        if (idx % t.stride != 0) return -1;
+    }
     if ((int)t.start.size() <= t.used) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
         t.start.push_back(a);
         t.stop.push_back(b);
+        t.sflops.push_back(0);
+        t.sbytes.push_back(0);
     }
     const int slot = t.used++;
-    t.flops_timed += flops;
-    t.bytes_timed += bytes;
+    t.sflops[slot] = flops;
+    t.sbytes[slot] = bytes;
     hipEventRecord(t.start[slot], s);
     return slot;
 }
@@ -63,7 +79,8 @@ extern "C" int trx_prof_reset(void) {
     for (int i = 0; i < PROF_NTAGS; ++i) {
         TagData& t = g_tags[i];
         t.used = 0;
-        t.launches = t.flops = t.bytes = t.flops_timed = t.bytes_timed = 0;
+        t.stride = 1;
+        t.launches = t.flops = t.bytes = 0;
     }
     return TRX_OK;
 }
@@ -72,19 +89,21 @@ extern "C" int trx_prof_reset(void) {
 extern "C" int trx_prof_get(int tag, double* out) {
     if (tag < 0 || tag >= PROF_NTAGS || !out) return TRX_ERR_ARG;
     TagData& t = g_tags[tag];
-    double ms = 0;
+    double ms = 0, fl = 0, by = 0;
     for (int i = 0; i < t.used; ++i) {
         if (hipEventSynchronize(t.stop[i]) != hipSuccess) return TRX_ERR_LAUNCH;
         float e = 0;
         if (hipEventElapsedTime(&e, t.start[i], t.stop[i]) != hipSuccess) return TRX_ERR_LAUNCH;
         ms += e;
+        fl += t.sflops[i];
+        by += t.sbytes[i];
     }
-    out[0] = t.launches; out[1] = t.used; out[2] = t.flops_timed; out[3] = t.bytes_timed; out[4] = ms; out[5] = t.flops;
+    out[0] = t.launches; out[1] = t.used; out[2] = fl; out[3] = by; out[4] = ms; out[5] = t.flops;
     return TRX_OK;
 }
 
 extern "C" const char* trx_prof_tag_name(int tag) {
-    static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "(retired tag)", "apply_window_kernel",
-                                            "qr_window_kernel", "hess_gemv_kernel"};
+    static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "qr_prepare_kernel", "apply_window_kernel",
+                                            "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }

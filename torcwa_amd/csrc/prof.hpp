@@ -5,11 +5,13 @@
 #include "common.hpp"
 
 namespace trx {
-enum ProfTag { PROF_GEMM_NN = 0, PROF_GEMM_OTHER = 1, PROF_QR_APPLY_LEFT = 2, PROF_QR_APPLY_RIGHT = 3, PROF_QR_WINDOW = 4,
-               PROF_HESS_GEMV = 5, PROF_NTAGS = 6 };
+enum ProfTag { PROF_GEMM_NN = 0, PROF_GEMM_OTHER = 1, PROF_QR_PREPARE = 2, PROF_QR_APPLY_RIGHT = 3, PROF_QR_WINDOW = 4,
+               PROF_HESS_GEMV = 5, PROF_HESS_COL = 6, PROF_LU_PANEL = 7, PROF_NTAGS = 8 };
 
 bool prof_enabled();
-// returns an event-slot handle (>= 0) or -1 when disabled / pool exhausted; records the start event
+// returns an event-slot handle (>= 0) or -1 when this launch is not sampled; records the start event.  Sampling is systematic:
+// every `stride`-th launch of a tag is timed; when the pool of event pairs is full, every other sample is dropped and the
+// stride doubles, so the timed launches stay spread uniformly over the whole run whatever its length.
 int prof_begin(int tag, hipStream_t s, double flops, double bytes);
 void prof_end(int tag, int slot, hipStream_t s);
 // adds algorithmic work that is only known after the launches ran (data-dependent kernels count it on the device)
