@@ -136,3 +136,30 @@ def test_eig_nonfinite_input_fails_fast(backend):
     w, V, info = run_eig(be, A)
     assert info[0] == 0 and info[1] > 0
     assert np.abs(A[0] @ V[0] - V[0] * w[0][None, :]).max() < 1e-10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_balances_badly_scaled_input(backend):
+    """zgebal parity (torch.linalg.eig -> zgeev balances first): A = D A0 D^-1 with D = 2^k, k in [-24, 24], has the eigenvalues
+    of the well-scaled A0, but entries spread over 28 orders of magnitude; an unbalanced QR iteration loses the small eigenvalues
+    to the norm of A (eps * 2^48 ~ 6e-2), the balanced one recovers them like LAPACK does.  Also: a matrix that is already
+    balanced must come through bit-identical scaling (D = I), and a batch mixes both kinds."""
+    be = get_backend(backend)
+    n = 48
+    A0 = RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)) + np.diag(4.0 * np.arange(n))
+    k = RNG.integers(-24, 25, size=n)
+    D = 2.0 ** k
+    A = np.stack([(D[:, None] * A0) / D[None, :], A0]).astype(np.complex128)
+    w, V, info = run_eig(be, A)
+    assert info[0] == 0 and info[1] == 0
+    wref, Vref = np.linalg.eig(A0)
+    assert match_eigs(w[0], wref) / np.abs(wref).max() < 1e-12
+    assert match_eigs(w[1], wref) / np.abs(wref).max() < 1e-12
+    # eigenvectors of the scaled matrix: columns of D V0, unit 2-norm (zgebak + normalisation)
+    for j in range(n):
+        i = int(np.argmin(np.abs(wref - w[0][j])))
+        v = D * Vref[:, i]
+        v /= np.linalg.norm(v)
+        assert abs(abs(np.vdot(v, V[0][:, j])) - 1.0) < 1e-9, j
+    assert np.allclose(np.linalg.norm(V[0], axis=0), 1.0, atol=1e-12)
+    check(A[1:], w[1:], V[1:], info[1:], 1e-13)

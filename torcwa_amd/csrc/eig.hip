@@ -1,7 +1,8 @@
 // trx_eig: batched general complex eigendecomposition A V = V diag(w) -- the MI355X replacement for the
 // torch.linalg.eig call behind torcwa's `Eig.apply` (torcwa/torch_eig.py:12-17, used at rcwa.py:1236/1238).
-// Pipeline: Hessenberg reduction (eig_hess.hip) -> multi-shift QR to Schur form (eig_qr.hip) -> triangular
-// eigenvectors + back-transform + unit-norm scaling (eig_vec.hip).
+// Pipeline (the stages of LAPACK zgeev: gebal -> gehrd/unghr -> hseqr -> trevc -> gebak -> normalise): balancing (eig_bal.hip) ->
+// Hessenberg reduction (eig_hess.hip) -> multi-shift QR to Schur form (eig_qr.hip) -> triangular eigenvectors + back-transform
+// + undo of the balancing + unit-norm scaling (eig_vec.hip).
 #include "eig.hpp"
 
 namespace trx {
@@ -21,6 +22,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * EigPlan::HNB);                               // tau
     tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U
     tot += al256(e * B * EigPlan::QNS);                               // shifts
+    tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
     tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
     return tot;
@@ -45,6 +47,9 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QNS);
+    Bf.bal_d = (T*)take(sizeof(T) * B * N);
+    Bf.bal_w = (T*)take(sizeof(T) * 3 * B * N);
+    Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
     Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
 }
@@ -63,7 +68,9 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     EigBuffers<T> B;
     eig_carve<T>(B, A, ws, n, batch);
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    int rc = hessenberg<T>(s, B, n, batch);
+    int rc = balance<T>(s, B, n, batch);          // A <- D^-1 A D (zgebal 'S'); undone on the eigenvectors in schur_vectors
+    if (rc) return rc;
+    rc = hessenberg<T>(s, B, n, batch);
     if (rc) return rc;
     TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
     rc = hessenberg_qr<T>(s, B, n, batch, info);

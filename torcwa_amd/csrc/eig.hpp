@@ -42,6 +42,9 @@ struct EigBuffers {
     cx<T>* tau;    // [B,HNB]
     cx<T>* U;      // [B,QW,QW] window unitary
     cx<T>* shifts; // [B,QNS]
+    T* bal_d;      // [B,n] balancing scale D (A_balanced = D^-1 A D)
+    T* bal_w;      // [2,B,n] balancing scratch: row norms, column norms (sized for 3)
+    int* bal_flags; // [B] per-matrix "needs balancing" flags (sized for 2B)
     QrState* st;   // [B]
     int* summary;  // [64]: 8 ints per iteration group of the QR phase (up to 8 groups)
 };
@@ -49,6 +52,7 @@ struct EigBuffers {
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, int batch);
 
+template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);

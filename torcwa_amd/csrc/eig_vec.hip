@@ -71,22 +71,24 @@ __global__ __launch_bounds__(256) void trevc_block_kernel(const cx<T>* __restric
         }
 }
 
-// column 2-norms: each block owns 64 columns and walks all rows (coalesced along rows)
+// V <- D V (undo of the balancing, zgebak: row r times d[r]) and unit column 2-norms in one pass: each block owns 64 columns and
+// walks all rows (coalesced along rows)
 template <class T>
-__global__ __launch_bounds__(256) void colnorm_scale_kernel(cx<T>* __restrict__ Vall, int n) {
+__global__ __launch_bounds__(256) void colnorm_scale_kernel(cx<T>* __restrict__ Vall, int n, const T* __restrict__ dall) {
     __shared__ T part[4][64];
     const int b = blockIdx.y;
     cx<T>* V = Vall + (long)b * n * n;
+    const T* d = dall + (long)b * n;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     T s = T(0);
     if (c < n)
-        for (int r = rg; r < n; r += 4) s += norm2(V[(long)r * n + c]);
+        for (int r = rg; r < n; r += 4) s += d[r] * d[r] * norm2(V[(long)r * n + c]);
     part[rg][threadIdx.x & 63] = s;
     __syncthreads();
     const T tot = part[0][threadIdx.x & 63] + part[1][threadIdx.x & 63] + part[2][threadIdx.x & 63] + part[3][threadIdx.x & 63];
     const T sc = tot > T(0) ? T(1) / sqrt(tot) : T(1);
     if (c < n)
-        for (int r = rg; r < n; r += 4) V[(long)r * n + c] = sc * V[(long)r * n + c];
+        for (int r = rg; r < n; r += 4) V[(long)r * n + c] = (sc * d[r]) * V[(long)r * n + c];
 }
 
 }  // namespace
@@ -110,7 +112,7 @@ int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>
     }
     int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, B.Z, n, nn, B.X, n, nn, zero, V, n, nn, batch, nullptr, 1);    // X upper triangular: half the K range
     if (rc) return rc;
-    TRX_LAUNCH((colnorm_scale_kernel<T>), dim3(cdiv_i(n, 64), batch), dim3(256), 0, s, V, n);
+    TRX_LAUNCH((colnorm_scale_kernel<T>), dim3(cdiv_i(n, 64), batch), dim3(256), 0, s, V, n, (const T*)B.bal_d);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
