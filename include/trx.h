@@ -12,9 +12,10 @@
  *  - All pointers are DEVICE pointers (HBM).  The library never allocates device memory and is stream-ordered and
  *    re-entrant: the caller owns every buffer including the workspace, whose size is returned by the matching
  *    *_ws_bytes() function.  Every entry point is asynchronous EXCEPT trx_eig, whose QR iteration is convergence-driven:
- *    it synchronises `stream` once per outer iteration to read back a 16-byte progress summary, and for batch >= 8 it
- *    runs the QR phase of 2-4 sub-batches on internal non-blocking streams (forked from and joined back into `stream`
- *    with events, created and destroyed inside the call) so that their latency-bound steps overlap.
+ *    it synchronises once per outer iteration (about n / 50 of them) to read back a 16-byte progress summary, and for
+ *    batch >= 8 it runs the QR phase of 2-4 sub-batches on internal non-blocking streams (forked from and joined back into
+ *    `stream` with events) so that their latency-bound steps overlap.  Those streams and events come from a process-wide
+ *    pool created on first use (nothing is created or destroyed per call), and no environment variable is read per call.
  *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
  *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
  */
@@ -69,6 +70,13 @@ int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* info, void*
 size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
+
+/* Tuning knobs of the QR phase of trx_eig (no reference counterpart).  Defaults are chosen from the batch size; the environment
+ * variables TRX_QR_GROUPS / TRX_SLAB_SPW / TRX_QR_AED / TRX_QR_NIBBLE / TRX_QR_MOVES / TRX_QR_CHAINS are read ONCE per process as
+ * initial values.  key: "qr_groups" (iteration groups, 1-8), "slab_spw" (strips per wave of the off-window update: 1, 2, 4),
+ * "qr_aed" (AED window, 16-64), "qr_nibble" (0-100), "qr_moves" (AED reordering bound), "qr_chains" (bulge chains per sweep, 1-3);
+ * value 0 = automatic.  Results do not depend on any of them (tests/test_eig.py).  Returns TRX_OK or TRX_ERR_ARG. */
+int trx_tuning(const char* key, int value);
 
 /* Adjoint of the eigendecomposition: torcwa/torch_eig.py:19-44 (`Eig.backward`, the Lorentzian-broadened formula)
  *   gA = (V^H)^-1 (diag(gw) + conj(F) o (V^H gV)) V^H,   F_ij = conj(w_j - w_i) / (|w_j - w_i|^2 + broadening), F_ii = 0.

@@ -38,6 +38,7 @@ inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipPeekAtLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }

@@ -113,16 +113,46 @@ def test_eig_four_iteration_groups_gpu():
     check(A, w, V, info, 1e-12)
 
 
+def _set_knobs(be, **kw):
+    for k, v in kw.items():
+        assert be.lib.tuning(k.encode(), int(v)) == 0, k
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("env", [{"TRX_QR_GROUPS": "3", "TRX_SLAB_SPW": "4"}, {"TRX_QR_GROUPS": "1", "TRX_SLAB_SPW": "1", "TRX_QR_AED": "32"}])
-def test_eig_tuning_knobs(backend, env, monkeypatch):
-    """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window) select different code paths, not results."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2)])
+def test_eig_tuning_knobs(backend, knobs):
+    """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window, bulge chains per sweep; include/trx.h:
+    trx_tuning) select different code paths, not results."""
     be = get_backend(backend)
     n, batch = 90, 9
     A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
-    w, V, info = run_eig(be, A)
+    try:
+        _set_knobs(be, **knobs)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, **{k: 0 for k in knobs})
+        _set_knobs(be, qr_nibble=100, qr_moves=12)
+    check(A, w, V, info, 1e-12)
+    assert be.lib.tuning(b"no_such_knob", 1) != 0 and be.lib.tuning(b"qr_chains", 9) != 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("chains", [3, 2, 1])
+def test_eig_multiple_bulge_chains(backend, chains):
+    """Active blocks long enough for three bulge chains per sweep (chain c follows chain c-1 one window behind; 48 of the AED
+    window's eigenvalues as shifts): a dense random matrix (slow deflation: the chains run the full length many times) and a
+    matrix with a spread diagonal (fast deflation: chains are re-planned as the block shrinks).  Same results with 1, 2, 3 chains."""
+    if backend == "emu" and chains != 3:
+        pytest.skip("emulator time budget: the three-chain path only")
+    be = get_backend(backend)
+    n = 420 if backend == "gpu" else 232          # emulator: two chains fit (one per 128 rows beyond the first 96)
+    A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex128)
+    A[1] = 0.3 * A[1] + np.diag(np.linspace(-20, 20, n)).astype(np.complex128)
+    try:
+        _set_knobs(be, qr_chains=chains)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, qr_chains=0)
     check(A, w, V, info, 1e-12)
 
 

@@ -20,8 +20,8 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * N * 2 * EigPlan::HNB) * 2;                   // YV, BC
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Sm
     tot += al256(e * B * EigPlan::HNB);                               // tau
-    tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U
-    tot += al256(e * B * EigPlan::QNS);                               // shifts
+    tot += al256(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);   // U
+    tot += al256(e * B * EigPlan::QKC * EigPlan::QNS);                // shifts
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
     tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
@@ -45,8 +45,8 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.BC = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
     Bf.Sm = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
-    Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
-    Bf.shifts = (cx<T>*)take(e * B * EigPlan::QNS);
+    Bf.U = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);
+    Bf.shifts = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QNS);
     Bf.bal_d = (T*)take(sizeof(T) * B * N);
     Bf.bal_w = (T*)take(sizeof(T) * 3 * B * N);
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
@@ -154,6 +154,11 @@ extern "C" int trx_eig_backward(int dtype, const void* w, const void* V, const v
         return trx::eig_backward_t<double>(s, (const cx<double>*)w, (const cx<double>*)V, (const cx<double>*)gw, (const cx<double>*)gV, broadening, n, batch,
                                       (cx<double>*)gA, piv, info, (cx<double>*)ws);
     return TRX_ERR_DTYPE;
+}
+
+extern "C" int trx_tuning(const char* key, int value) {
+    if (!key) return TRX_ERR_ARG;
+    return trx::qr_set_knob(key, value);
 }
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {

@@ -7,7 +7,8 @@ namespace trx {
 struct EigPlan {
     static constexpr int HNB = 32;     // Hessenberg panel width
     static constexpr int QW = 64;      // QR window size (rows/cols staged in LDS)
-    static constexpr int QNS = 16;     // shifts (= bulges) per sweep, spaced 2 rows apart
+    static constexpr int QNS = 16;     // shifts (= bulges) per CHAIN, spaced 2 rows apart
+    static constexpr int QKC = 3;      // bulge chains per sweep (each in its own window, at least one window apart)
     static constexpr int QNMIN = 64;   // active blocks up to this size are finished by the in-LDS explicit-shift QR (one wave)
     static constexpr int QAED = 64;    // aggressive-early-deflation window (<= QNMIN, <= 64: one lane per column)
     static constexpr int VNB = 32;     // block height of the triangular eigenvector back-substitution
@@ -15,13 +16,16 @@ struct EigPlan {
 
 // per-matrix iteration state of the QR phase (device resident)
 struct QrState {
-    int ilo, ihi;        // active block (inclusive)
-    int k;               // number of shifts of the running sweep
-    int tau, tau_last;   // global chase step: bulge s sits at p = ilo + tau - 2 s
-    int mode;            // see QR_* below
+    int ilo, ihi;                 // active block (inclusive)
+    int nch;                      // bulge chains of the running sweep (chain 0 runs ahead, chain c follows chain c-1)
+    int k[EigPlan::QKC];          // shifts of each chain
+    int tau[EigPlan::QKC][2];     // chase step of each chain: bulge s of chain c sits at p = ilo + tau - 2 s.  Double-buffered by the
+                                  // parity of the window step: a step reads [par] and writes [par ^ 1] (chain c looks at chain c-1)
+    int tau_last[EigPlan::QKC];
+    int mode;                     // see QR_* below
     int stall, sweeps;
-    int w0, w1;          // window of the last window step: the pending off-window update acts on [w0, w1)
-    int fail;            // number of unconverged eigenvalues on failure
+    int w0[EigPlan::QKC], w1[EigPlan::QKC];   // window of each chain's last step: its pending off-window update acts on [w0, w1)
+    int fail;                     // number of unconverged eigenvalues on failure
     int pad;
 };
 enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
@@ -40,8 +44,8 @@ struct EigBuffers {
     cx<T>* BC;     // [B,2*HNB,n]   [Vt^H ; T^H W]
     cx<T>* Sm;     // [B,HNB,HNB]   V^H Y
     cx<T>* tau;    // [B,HNB]
-    cx<T>* U;      // [B,QW,QW] window unitary
-    cx<T>* shifts; // [B,QNS]
+    cx<T>* U;      // [B,QKC,QW,QW] window unitary of each chain
+    cx<T>* shifts; // [B,QKC,QNS]
     T* bal_d;      // [B,n] balancing scale D (A_balanced = D^-1 A D)
     T* bal_w;      // [2,B,n] balancing scratch: row norms, column norms (sized for 3)
     int* bal_flags; // [B] per-matrix "needs balancing" flags (sized for 2B)
@@ -55,6 +59,7 @@ template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, in
 template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
+int qr_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 
 }  // namespace trx

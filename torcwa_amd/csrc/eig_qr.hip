@@ -9,22 +9,33 @@
 // progress (active block, shifts, chase position) lives in device memory, so one fixed launch schedule serves the
 // whole batch; matrices that have nothing to do in a step see an empty window and exit.
 //
-//   qr_prepare_kernel  (1 wave / matrix)  deflation scan, active-block bookkeeping, shifts = eigenvalues of the
-//                                         trailing k x k block (in-LDS single-shift QR); blocks <= QNMIN are
-//                                         finished here by the same in-LDS QR with U accumulated.
-//   qr_window_kernel   (256 thr / matrix) one window step of the bulge chain.
-//   apply_window_kernel  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n] ;  H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;
-//                        Z[:, w0:w1] <- Z[:, w0:w1] U        (one launch, disjoint slabs, MFMA)
+//   qr_prepare_kernel  (1 wave / matrix)  deflation scan, active-block bookkeeping, aggressive early deflation on the
+//                                         trailing window (in-LDS single-shift QR), shifts for up to QKC chains; blocks
+//                                         <= QNMIN are finished here by the same in-LDS QR with U accumulated.
+//   qr_window_kernel   (1 workgroup per matrix AND chain) one window step of each bulge chain.
+//   apply_window_kernel<PART 0>  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n]                                   (left updates, all chains)
+//   apply_window_kernel<PART 1>  H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U     (right updates, all chains)
+//
+// Several bulge chains per sweep.  A sweep sends up to QKC chains of QNS shifts each down the active block, chain c following
+// chain c-1 at a distance of at least one window (a chain moves only if its new window ends above the last bulge of the chain
+// ahead), so that one window step advances all of them: their windows are disjoint diagonal blocks (independent workgroups), the
+// left updates of different chains touch disjoint rows and the right updates disjoint columns.  A block that two chains both
+// reach (rows of the upper window x columns of the lower one) gets U_a^H from the left in PART 0 and U_b from the right in PART 1
+// -- the two commute, and the two launches order them.  Up to 48 of the AED window's eigenvalues are thus used per sweep
+// instead of 16: a third of the AED calls and of the latency-bound window steps for the same number of shifts.
 #include "eig.hpp"
 #include <cstdlib>
 #include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
 #include "mfma.hpp"
 #include "prof.hpp"
 
 namespace trx {
 namespace {
 
-constexpr int QW = EigPlan::QW, QNS = EigPlan::QNS, QNMIN = EigPlan::QNMIN;
+constexpr int QW = EigPlan::QW, QNS = EigPlan::QNS, QNMIN = EigPlan::QNMIN, QKC = EigPlan::QKC;
 constexpr int SM = 64;             // largest matrix the in-LDS single-wave routines handle (one lane per column)
 constexpr int SLD = SM + 1;        // leading dimension of the small in-LDS matrices
 constexpr int QAED = EigPlan::QAED;   // aggressive-early-deflation window
@@ -265,16 +276,45 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_init_kernel(QrState* __restrict__ st, int n) {
     if (threadIdx.x == 0) {
         QrState s;
-        s.ilo = 0; s.ihi = n - 1; s.k = 0; s.tau = 0; s.tau_last = -1; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0;
-        s.w0 = 0; s.w1 = 0; s.fail = 0; s.pad = 0;
+        s.ilo = 0; s.ihi = n - 1; s.nch = 0; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0; s.fail = 0; s.pad = 0;
+        for (int c = 0; c < QKC; ++c) { s.k[c] = 0; s.tau[c][0] = s.tau[c][1] = 1; s.tau_last[c] = 0; s.w0[c] = 0; s.w1[c] = 0; }
         st[blockIdx.x] = s;
     }
 }
 
+__device__ __forceinline__ void clear_windows(QrState& st) {
+#pragma unroll
+    for (int c = 0; c < QKC; ++c) { st.w0[c] = 0; st.w1[c] = 0; }
+}
+
+// Lay out the chains of a sweep over an active block of m rows with `avail` shifts at hand: one chain per 128 rows of room
+// beyond the first window (a follower needs ~3 window steps = 93 rows of distance), QNS shifts per chain, at most max_chains.
+// Returns the total number of shifts; chain c (0 = first to run) gets k[c] of them.
+__device__ __forceinline__ int plan_chains(QrState& st, int ilo, int ihi, int avail, int max_chains) {
+    const int m = ihi - ilo + 1;
+    int room = 1 + (m > 96 ? (m - 96) / 128 : 0);
+    if (room > max_chains) room = max_chains;
+    int ktot = avail < QNS * room ? avail : QNS * room;
+    if (ktot < 0) ktot = 0;
+    st.nch = (ktot + QNS - 1) / QNS;
+#pragma unroll
+    for (int c = 0; c < QKC; ++c) {
+        int kc = ktot - QNS * c;
+        kc = kc < 0 ? 0 : (kc > QNS ? QNS : kc);
+        st.k[c] = kc;
+        if (kc > 0) { st.tau[c][0] = st.tau[c][1] = 0; st.tau_last[c] = (ihi - 1 - ilo) + 2 * (kc - 1); }
+        else { st.tau[c][0] = st.tau[c][1] = 1; st.tau_last[c] = 0; }
+    }
+    return ktot;
+}
+// position (0 = top of the shift list, ktot-1 = bottom-most eigenvalue) of shift s of chain c: chain 0 takes the bottom QNS
+__device__ __forceinline__ int chain_shift_pos(const QrState& st, int ktot, int c, int s) { return ktot - QNS * c - st.k[c] + s; }
+
 template <class T>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
-                                                        int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, long long* dbg_all = nullptr) {
+                                                        int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
+                                                        long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
@@ -290,6 +330,15 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     __syncthreads();
     QrState st = sst;
     if (st.mode == QR_DONE) return;
+    if (st.mode == QR_CHASE) {
+        // safety net: a chain that has not reached the bottom yet (the host's step count is a bound, not a guarantee) -- ask for more steps
+        bool unfinished = false;
+        for (int c = 0; c < st.nch; ++c) unfinished = unfinished || (st.tau[c][par] <= st.tau_last[c]);
+        if (unfinished) {
+            if (lane == 0) { atomicAdd(&summary[0], 1); atomicOr(&summary[2], 2); atomicMax(&summary[1], st.ihi - st.ilo + 1); }
+            return;
+        }
+    }
     const T ulp = eps_of<T>::value;
     // 1. deflation scan (negligible subdiagonals -> exact zeros).  A non-finite entry (NaN/Inf input, e.g. from a singular
     //    convolution matrix upstream) can never deflate: report the whole active block as failed instead of iterating to the
@@ -307,7 +356,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     __syncthreads();
     if (__any(bad)) {
-        if (lane == 0) { st.fail += st.ihi + 1; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
+        if (lane == 0) { st.fail += st.ihi + 1; st.mode = QR_DONE; clear_windows(st); stall_[b] = st; }
         return;
     }
     // 2. new ihi = largest i in [1, ihi] with a non-zero subdiagonal (0 if none)
@@ -320,7 +369,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         if (mask) { ihi = base - __builtin_ctzll(mask); break; }
     }
     if (ihi <= 0) {
-        if (lane == 0) { st.ihi = 0; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
+        if (lane == 0) { st.ihi = 0; st.mode = QR_DONE; clear_windows(st); stall_[b] = st; }
         return;
     }
     // 3. ilo = largest i in [1, ihi-1] with a zero subdiagonal (0 if none)
@@ -345,14 +394,15 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         __syncthreads();
         const bool ok = small_schur<T>(Hs, m, Us, rots);
         __syncthreads();
-        cx<T>* U = Uall + (long)b * QW * QW;
+        cx<T>* U = Uall + (long)b * QKC * QW * QW;            // chain slot 0 carries the unitary of a finished block / AED window
         for (int e = lane; e < m * m; e += 64) {
             const int r = e / m, c = e - r * m;
             H[(long)(ilo + r) * n + ilo + c] = (r <= c) ? Hs[r * SLD + c] : cx<T>(T(0), T(0));
             U[r * QW + c] = Us[r * SLD + c];
         }
         if (lane == 0) {
-            st.w0 = ilo; st.w1 = ihi + 1; st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
+            clear_windows(st);
+            st.w0[0] = ilo; st.w1[0] = ihi + 1; st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
             if (!ok) st.fail += m;
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
@@ -362,7 +412,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     // ---- aggressive early deflation on the trailing nw x nw window (Braman/Byers/Mathias; LAPACK zlaqr3) ----------
     if (st.sweeps >= max_sweeps) {
-        if (lane == 0) { st.fail += ihi + 1; st.mode = QR_DONE; st.w0 = st.w1 = 0; stall_[b] = st; }
+        if (lane == 0) { st.fail += ihi + 1; st.mode = QR_DONE; clear_windows(st); stall_[b] = st; }
         return;
     }
     const int nw = aed_w;                       // aed_w <= QAED <= QNMIN < m here, so the window is strictly inside the active block
@@ -401,22 +451,27 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     const int nd = nw - ns;
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[8] += t1 - tk0; tk0 = t1; dbg[11] += 1; }     // spike test + reordering
-    cx<T>* sh = shifts_all + (long)b * QNS;
+    cx<T>* sh = shifts_all + (long)b * QKC * QNS;
     if (nd == 0) {
         // nothing deflates: H is untouched; the window's eigenvalues (bottom k of them) are the shifts of a full sweep
-        const int k = (m / 2 < QNS) ? m / 2 : QNS;
-        if (lane < k) {
-            cx<T> sv = Hs[(nw - k + lane) * SLD + nw - k + lane];
-            if (st.stall > 0 && (st.stall % 6) == 0) {
-                const T mag = T(0.75) * cabs(H[(long)ihi * n + ihi - 1]);
-                const T ang = T(6.283185307179586) * (T)lane / (T)k;
-                sv = sv + cx<T>(mag * (T)cos(ang), mag * (T)sin(ang));
+        int avail = m / 2 < nw ? m / 2 : nw;
+        const int k = plan_chains(st, ilo, ihi, avail, max_chains);
+        {
+            const int c = lane / QNS, sidx = lane - c * QNS;
+            if (c < st.nch && sidx < st.k[c]) {
+                const int pos = nw - k + chain_shift_pos(st, k, c, sidx);
+                cx<T> sv = Hs[pos * SLD + pos];
+                if (st.stall > 0 && (st.stall % 6) == 0) {
+                    const T mag = T(0.75) * cabs(H[(long)ihi * n + ihi - 1]);
+                    const T ang = T(6.283185307179586) * (T)lane / (T)k;
+                    sv = sv + cx<T>(mag * (T)cos(ang), mag * (T)sin(ang));
+                }
+                sh[c * QNS + sidx] = sv;
             }
-            sh[lane] = sv;
         }
         if (lane == 0) {
-            st.k = k; st.tau = 0; st.tau_last = (ihi - 1 - ilo) + 2 * (k - 1); st.mode = QR_CHASE;
-            st.stall += 1; st.sweeps += 1; st.w0 = st.w1 = 0;
+            st.mode = QR_CHASE;
+            st.stall += 1; st.sweeps += 1; clear_windows(st);
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
             atomicMax(&summary[1], m);
@@ -429,10 +484,14 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     // as shifts of a sweep in the SAME outer iteration (first window slot applies V, the following ones chase).
     const int m2 = (ihi - nd) - ilo + 1;
     int kch = 0;
+    QrState stc = st;                       // chain layout of the sweep that follows the AED (committed below if it is taken)
     if (nd * 100 < nibble * nw && m2 > QNMIN && ns >= 2) {
-        kch = (m2 / 2 < QNS) ? m2 / 2 : QNS;
-        if (kch > ns) kch = ns;
-        if (lane < kch) sh[lane] = Hs[(ns - kch + lane) * SLD + ns - kch + lane];     // eigenvalues, before the restore below
+        kch = plan_chains(stc, ilo, ihi - nd, (m2 / 2 < ns) ? m2 / 2 : ns, max_chains);
+        const int c = lane / QNS, sidx = lane - c * QNS;
+        if (kch >= 2 && c < stc.nch && sidx < stc.k[c]) {
+            const int pos = ns - kch + chain_shift_pos(stc, kch, c, sidx);
+            sh[c * QNS + sidx] = Hs[pos * SLD + pos];                                 // eigenvalues, before the restore below
+        }
     }
     if (ns > 1 && (spike.x != T(0) || spike.y != T(0))) {
         // reflector that maps the spike s*conj(V[0,0:ns]) onto e1, then return T[0:ns,0:ns] to Hessenberg form
@@ -453,7 +512,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[9] += t1 - tk0; tk0 = t1; }       // Hessenberg restore
     {
-        cx<T>* U = Uall + (long)b * QW * QW;
+        cx<T>* U = Uall + (long)b * QKC * QW * QW;
         for (int e = lane; e < nw * nw; e += 64) {
             const int r = e / nw, c = e - r * nw;
             cx<T> v = Hs[r * SLD + c];
@@ -463,16 +522,18 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         }
         if (lane == 0) {
             H[(long)kw * n + kw - 1] = spike * conj(Us[0]);
-            st.w0 = kw; st.w1 = ihi + 1; st.stall = 0;
             if (kch >= 2) {
+                const int sw = st.sweeps;
+                st = stc;                      // chains planned above (k, tau, tau_last per chain)
                 st.mode = QR_AED_CHASE;
                 st.ihi = ihi - nd;
-                st.k = kch; st.tau = 0; st.tau_last = (st.ihi - 1 - ilo) + 2 * (kch - 1);
-                st.sweeps += 1;
+                st.sweeps = sw + 1;
                 atomicMax(&summary[1], m2);
             } else {
                 st.mode = QR_SMALL_PENDING;
             }
+            clear_windows(st);
+            st.w0[0] = kw; st.w1[0] = ihi + 1; st.stall = 0;
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
             atomicOr(&summary[2], 1);
@@ -481,7 +542,16 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
 }
 
-// One window step of the bulge chain.  Thread layout: QNS groups of LPB lanes, group s owns bulge s: its lanes compute the
+// Window of a chain whose chase step is tau: starts one row above its last bulge (clamped to the active block), QW wide.
+__device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, int tau_last, int& w0, int& w1, int& tau_end) {
+    w0 = ilo + tau - 2 * (k - 1) - 1;
+    if (w0 < ilo) w0 = ilo;
+    w1 = w0 + QW;
+    if (w1 > ihi + 1) w1 = ihi + 1;
+    tau_end = (w1 == ihi + 1) ? tau_last : (w1 - 3 - ilo);
+}
+
+// One window step of one bulge chain (blockIdx.x = chain, blockIdx.y = matrix).  Thread layout: QNS groups of LPB lanes, group s owns bulge s: its lanes compute the
 // rotation redundantly (no broadcast barrier), then stride over the window's columns (left rotation) and, after one barrier,
 // over its rows and the rows of U (right rotation).  Two barriers per chain step.  LPB = 64 (one wave per bulge, 1024
 // threads): a chain step is bound by the fp64 vector issue time of the 2 + 4 rotated element pairs per lane-quartet (cycle
@@ -492,32 +562,45 @@ constexpr int WTHREADS = QNS * LPB;        // threads of the window kernel
 constexpr int WIT = QW / LPB;              // element pairs per lane and phase
 template <class T>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
-    long long* dbg = (dbg_all && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;     // TRX_QR_DEBUG: cycle counters of matrix 0
+    long long* dbg = (dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;     // TRX_QR_DEBUG: cycle counters of matrix 0, chain 0
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
     cx<T>* Uw = Hw + QW * LD;                          // [QW][LD]
     QrState& sst = *reinterpret_cast<QrState*>(Uw + QW * LD);
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) sst = st_all[b];
     __syncthreads();
     const QrState st = sst;
-    if (st.mode == QR_SMALL_PENDING) { if (t == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }
-    if (st.mode == QR_AED_CHASE) { if (t == 0) st_all[b].mode = QR_CHASE; return; }      // this slot applies the AED unitary
-    if (st.mode != QR_CHASE || st.tau > st.tau_last) {
-        if (t == 0 && (st.w0 != 0 || st.w1 != 0)) { st_all[b].w0 = 0; st_all[b].w1 = 0; }
+    // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
+    // positions go to the [par] copy, which nobody writes in this step.
+    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
+    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) st_all[b].mode = QR_CHASE; return; }                  // this slot applies the AED unitary
+    const int tau0 = st.tau[ch][par];
+    bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
+    const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
+    int w0 = 0, w1 = 0, tau_end = 0;
+    if (move) {
+        chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
+        if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
+            // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
+            // this step); this chain may only work strictly above it
+            int p0, p1, pe;
+            chain_window(ilo, ihi, st.k[ch - 1], st.tau[ch - 1][par], st.tau_last[ch - 1], p0, p1, pe);
+            if (w1 > p0) move = false;
+        }
+    }
+    if (!move) {
+        if (t == 0) {
+            if (st.w0[ch] != 0 || st.w1[ch] != 0) { st_all[b].w0[ch] = 0; st_all[b].w1[ch] = 0; }
+            st_all[b].tau[ch][par ^ 1] = tau0;
+        }
         return;
     }
     cx<T>* H = Aall + (long)b * n * n;
-    const int k = st.k, ilo = st.ilo, ihi = st.ihi;
-    int w0 = ilo + st.tau - 2 * (k - 1) - 1;
-    if (w0 < ilo) w0 = ilo;
-    int w1 = w0 + QW;
-    if (w1 > ihi + 1) w1 = ihi + 1;
     const int ww = w1 - w0;
-    const int tau_end = (w1 == ihi + 1) ? st.tau_last : (w1 - 3 - ilo);
     {
         // window load: QW*QW/WTHREADS independent (clamped) global loads per thread in flight, then the LDS fill
         constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;      // rows per thread, row stride between them
@@ -539,14 +622,14 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
     }
     const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
-    const cx<T> shift = (sb < k) ? shifts_all[(long)b * QNS + sb] : cx<T>(T(0), T(0));
+    const cx<T> shift = (sb < k) ? shifts_all[((long)b * QKC + ch) * QNS + sb] : cx<T>(T(0), T(0));
     __syncthreads();
     if (dbg) { const long long t1 = clock64(); dbg[12] += t1 - tk0; tk0 = t1; }
     // Every phase of a chain step touches WIT element pairs per lane: the loops are fully unrolled with clamped LDS reads issued
     // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
     // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
     // barrier absorbs the skew.)
-    for (int tau = st.tau; tau <= tau_end; ++tau) {
+    for (int tau = tau0; tau <= tau_end; ++tau) {
         const int p = ilo + tau - 2 * sb;
         const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
         const int q = p - w0;
@@ -603,8 +686,8 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         __syncthreads();
         if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
     }
-    if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - st.tau + 1; tk0 = clock64(); }
-    cx<T>* U = Uall + (long)b * QW * QW;
+    if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
+    cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
     {
         constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
         const int c = t & (QW - 1), r4 = t / QW;
@@ -619,7 +702,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             }
         }
     }
-    if (t == 0) { st_all[b].tau = tau_end + 1; st_all[b].w0 = w0; st_all[b].w1 = w1; }
+    if (t == 0) { st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1; }
     if (dbg) dbg[14] += clock64() - tk0;
 }
 
@@ -644,12 +727,15 @@ struct SlabStrip {       // wave-uniform description of one strip
     int a0, lim;         // first column / row of the strip, end of the valid column / row range
 };
 
-template <class T>
+// strip g of PART 0 (left update: nL strips of 16 columns of H right of the window), PART 1 (right updates: nR strips of 16
+// rows of H above the window, then the strips of Z) or PART 2 (everything: left | right-H | Z)
+template <class T, int PART>
 __device__ __forceinline__ SlabStrip<T> slab_locate(int g, int nL, int nR, cx<T>* H, cx<T>* Z, int n, int w0, int w1) {
     SlabStrip<T> d;
-    if (g < nL) { d.X = H; d.side = 0; d.a0 = w1 + 16 * g; d.lim = n; }
-    else if (g < nL + nR) { d.X = H; d.side = 1; d.a0 = 16 * (g - nL); d.lim = w0; }
-    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nL - nR); d.lim = n; }
+    if (PART == 2) { if (g < nL) { d.X = H; d.side = 0; d.a0 = w1 + 16 * g; d.lim = n; return d; } g -= nL; }
+    if (PART == 0) { d.X = H; d.side = 0; d.a0 = w1 + 16 * g; d.lim = n; }
+    else if (g < nR) { d.X = H; d.side = 1; d.a0 = 16 * g; d.lim = w0; }
+    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nR); d.lim = n; }
     return d;
 }
 
@@ -758,31 +844,34 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
     }
 }
 
-// One launch per window step updates everything off the window.  blockIdx.y = matrix; a workgroup takes 4*SPW consecutive
-// strips (its 4 waves interleaved, so that they stream neighbouring rows), ordered left | right-H | right-Z.
+// Off-window updates of a window step.  With ONE chain per sweep (the default) a single launch does everything (PART 2: the
+// regions are disjoint).  With several chains two launches order the left updates (PART 0) before the right updates of H and Z
+// (PART 1), see the note at the top.  blockIdx.y = matrix, blockIdx.x = chain * nslab + strip group; a workgroup takes 4*SPW
+// consecutive strips of ONE chain (its 4 waves interleaved, so that they stream neighbouring rows).
 // SPW = strips per wave (a workgroup covers 4*SPW strips): 1 gives the shortest dependent chain per launch and the most
 // workgroups (what matters when several iteration groups keep the GPU busy with small launches); larger values amortise the
 // U prologue (64 KiB from L2 per workgroup) over more streamed data.
-template <class T, int SPW>
+template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n,
                                                            const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work) {
+                                                           unsigned* __restrict__ work, int nslab) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
     const int b = blockIdx.y;
-    const int w0 = st_all[b].w0, w1 = st_all[b].w1;
+    const int ch = blockIdx.x / nslab, gx = blockIdx.x - ch * nslab;
+    const int w0 = st_all[b].w0[ch], w1 = st_all[b].w1[ch];
     const int ww = w1 - w0;
     if (ww <= 0) return;
     const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
-    const int S = nL + nR + nZ;
-    const int g0 = blockIdx.x * (4 * SPW);
+    const int S = PART == 0 ? nL : (PART == 1 ? nR + nZ : nL + nR + nZ);
+    const int g0 = gx * (4 * SPW);
     if (g0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
-    if (blockIdx.x == 0 && t == 0)                   // algorithmic work of this matrix' update, in units of 4096 complex MACs
+    if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
         atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
-    const cx<T>* U = Uall + (long)b * QW * QW;
+    const cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
     for (int e = t; e < QW * QW; e += 256) {
         const int k = e >> 6, c = e & 63;
         cx<T> u(T(0), T(0));
@@ -795,9 +884,9 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     for (int i = 0; i < SPW; ++i) {
         const int g = g0 + wave + 4 * i;
         if (g >= S) break;
-        const SlabStrip<T> d = slab_locate<T>(g, nL, nR, H, Z, n, w0, w1);
-        if (d.side == 1) slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
-        else slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+        const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
+        if (PART == 0 || (PART == 2 && d.side == 0)) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+        else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
     }
 }
 
@@ -809,59 +898,134 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 }  // namespace
 
+// ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
+struct QrKnobs {
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0;
+    bool debug = false;
+};
+static QrKnobs& qr_knobs() {
+    static QrKnobs k = [] {
+        QrKnobs q;
+        auto geti = [](const char* name, int lo, int hi, int dflt) {
+            const char* e = getenv(name);
+            if (!e) return dflt;
+            const int v = atoi(e);
+            return (v >= lo && v <= hi) ? v : dflt;
+        };
+        q.groups = geti("TRX_QR_GROUPS", 1, 8, 0);            // 0 = by batch size
+        q.spw = geti("TRX_SLAB_SPW", 1, 4, 0);
+        if (q.spw == 3) q.spw = 0;
+        q.aed = geti("TRX_QR_AED", 16, QAED, 0);
+        q.nibble = geti("TRX_QR_NIBBLE", 0, 100, 100);
+        q.moves = geti("TRX_QR_MOVES", 0, QAED, QAED_MOVES);
+        q.chains = geti("TRX_QR_CHAINS", 1, QKC, 0);
+        q.debug = getenv("TRX_QR_DEBUG") != nullptr;
+        return q;
+    }();
+    return k;
+}
+
+// Non-blocking streams and timing-less events for the iteration groups, created on first use and kept for the life of the
+// process (per device); a call checks out what it needs and hands it back, so concurrent callers never share one.
+struct QrLane { hipStream_t s = nullptr; hipEvent_t ev = nullptr; int dev = -1; bool has_stream = false; };
+static std::mutex g_lane_mu;
+static std::vector<QrLane> g_lane_free;
+static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
+    {
+        std::lock_guard<std::mutex> lock(g_lane_mu);
+        for (size_t i = 0; i < g_lane_free.size(); ++i)
+            if (g_lane_free[i].dev == dev && g_lane_free[i].has_stream == want_stream) { out = g_lane_free[i]; g_lane_free.erase(g_lane_free.begin() + i); return true; }
+    }
+    out = QrLane();
+    out.dev = dev;
+    out.has_stream = want_stream;
+    if (want_stream && hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&out.ev, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+static void lane_return(const QrLane& l) {
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    g_lane_free.push_back(l);
+}
+
+// trx_tuning(): the environment variables only provide the defaults (read once); this sets a knob explicitly.  0 = automatic.
+int qr_set_knob(const char* key, int value) {
+    QrKnobs& k = qr_knobs();
+    const std::string s(key);
+    int* slot = nullptr;
+    int lo = 0, hi = 0;
+    if (s == "qr_groups") { slot = &k.groups; hi = 8; }
+    else if (s == "slab_spw") { slot = &k.spw; hi = 4; }
+    else if (s == "qr_aed") { slot = &k.aed; hi = QAED; }
+    else if (s == "qr_nibble") { slot = &k.nibble; hi = 100; }
+    else if (s == "qr_moves") { slot = &k.moves; hi = QAED; }
+    else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
+    else return TRX_ERR_ARG;
+    if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
+    *slot = value;
+    return TRX_OK;
+}
+
 template <class T>
 int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info) {
     constexpr int LD = QW + 1;
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
+    const QrKnobs& K = qr_knobs();
     const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
     const size_t smw = sm2 + sizeof(QrState);
     const size_t sma = sizeof(T) * 2 * QW * MLD;
     const size_t smp = sizeof(cx<T>) * (2 * SM * SLD + 2 * SM) + sizeof(Rot<T>) * SM + sizeof(QrState);
-    if (set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2>, sma) ||
-        set_max_dyn_smem((const void*)apply_window_kernel<T, 4>, sma) ||
-        set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp))
-        return TRX_ERR_LAUNCH;
+    static std::once_flag attr_once[2];
+    int attr_rc = 0;
+    std::call_once(attr_once[sizeof(T) == 8], [&] {
+        attr_rc = set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) ||
+                  set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp);
+    });
+    if (attr_rc) return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
     if (hipMemsetAsync(B.summary, 0, sizeof(int) * 64, s) != hipSuccess) return TRX_ERR_LAUNCH;
     const int max_sweeps = 30 * n + 100;
-    // strips per wave of the slab kernel: measured at batch 128 with 4 iteration groups (final state): 1: 25.7, 2: 26.1-26.4,
-    // 4: 26.6-26.7 solves/s; small batches are latency bound and keep the shorter per-launch chain
-    int spw = batch >= 64 ? 4 : 2;
-    if (const char* e = getenv("TRX_SLAB_SPW")) {            // tuning knob: 1, 2 or 4 strips per wave
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) spw = v;
-    }
-    const int nslabwg = cdiv_i(2 * cdiv_i(n, 16) + 2, 4 * spw);   // workgroups per matrix: left + right-H strips <= n/16 + 2, Z strips = n/16
-    const int adv = QW - 2 * QNS - 1;                 // guaranteed chain advance per window step
+    // strips per wave of the slab kernel: small batches are latency bound and keep the shorter per-launch chain
+    const int spw = K.spw ? K.spw : (batch >= 64 ? 4 : 2);
+    const int nstrip = cdiv_i(n, 16);
+    const int nslabL = cdiv_i(nstrip + 1, 4 * spw);          // workgroups per matrix and chain: left strips <= n/16 + 1
+    const int nslabR = cdiv_i(2 * nstrip + 1, 4 * spw);      // right-H strips <= n/16 + 1, Z strips = n/16
+    const int adv = QW - 2 * QNS - 1;                        // guaranteed chain advance per window step
+    const int nslabA = cdiv_i(2 * nstrip + 2, 4 * spw);      // single-launch variant: all strips of one chain
+    // Bulge chains per sweep.  Measured on MI355X (n = 1922): 2 / 3 chains cut the outer iterations by only 31 / 36 % (the AED's
+    // deflation yield, not the shift count, paces the iteration) while the slab work grows by a third, and the two-launch
+    // update they need costs 10 % on its own: 26.5 (1 chain, one launch) vs 22.1 / 21.9 solves/s at batch 128, 12.1 vs 11.3 at
+    // batch 16.  One chain is the default; the knob stays for other spectra.
+    const int kc = K.chains ? K.chains : 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
-    // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix) run while the slab updates of
-    // the other groups fill the matrix cores.  One host thread drives all of them round-robin; per visit it reads the 16-byte
+    // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
+    // of the other groups fill the matrix cores.  One host thread drives all of them round-robin; per visit it reads the 16-byte
     // summary of the group's last prepare (normally long finished: the prepare is queued right behind the group's sweep),
     // queues the next sweep and the prepare after it, and moves on.
     constexpr int MAXG = 8;
     struct Group {
+        QrLane lane;           // stream (null: the caller's) + event
         hipStream_t s;
-        hipEvent_t ev;         // start stagger / join
         int b0, nb;
         int* summary;          // device, 8 ints: [0] active matrices, [1] largest chase length, [2] flags, [3] slab work (cumulative)
         bool done;
         unsigned work;
+        int par;               // parity of the next window step (double-buffered chase positions)
     };
     // 4 groups = the number of hardware queues a HIP process gets by default; beyond that streams share queues and serialise
-    // (measured: 2 groups 21.1, 4 groups 21.8, 6 groups 18.6, 8 groups 18.0 solves/s at batch 128)
-    int ngroups = batch >= 64 ? 4 : (batch >= 8 ? 2 : 1);
-    if (const char* e = getenv("TRX_QR_GROUPS")) {          // tuning knob (1..8)
-        const int v = atoi(e);
-        if (v >= 1 && v <= MAXG) ngroups = v;
-    }
+    int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
     if (ngroups > batch) ngroups = batch;
     Group grp[MAXG];
-    int rc = TRX_OK;
-    hipEvent_t ev_fork = nullptr;
-    for (int g = 0; g < ngroups; ++g) { grp[g].s = nullptr; grp[g].ev = nullptr; }
+    int rc = TRX_OK, dev = 0, nlanes = 0;
+    (void)hipGetDevice(&dev);
+    QrLane fork;
     if (ngroups > 1) {
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_fork, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        if (!lane_checkout(dev, false, fork) || hipEventRecord(fork.ev, s) != hipSuccess) return TRX_ERR_LAUNCH;
     }
     for (int g = 0; g < ngroups; ++g) {
         Group& G = grp[g];
@@ -870,45 +1034,34 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.summary = B.summary + 8 * g;
         G.done = false;
         G.work = 0;
-        if (g == 0) { G.s = s; }
-        else if (hipStreamCreateWithFlags(&G.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(G.s, ev_fork, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-        if (ngroups > 1 && hipEventCreateWithFlags(&G.ev, hipEventDisableTiming) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+        G.par = 0;
+        if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
+        ++nlanes;
+        G.s = g == 0 ? s : G.lane.s;
+        if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
-    // AED window: 64 deflates most per call (fewest sweeps, least slab work) but costs 3.2 ms of single-wave latency; at small
-    // batches, where nothing is throughput bound, a smaller window shortens the chain (prototype: 48 -> +16 % shift-rows, -55 % AED time)
-    int aed_w = batch >= 64 ? QAED : 48;        // measured: batch 16: 64 -> 1.79 s, 48 -> 1.73 s, 32 -> 1.77 s per step; batch 128: 5.11 / 5.13 / 5.44 s
-    if (const char* e = getenv("TRX_QR_AED")) {
-        const int v = atoi(e);
-        if (v >= 16 && v <= QAED) aed_w = v;
-    }
-    // LAPACK skips the sweep when AED deflated more than 14 % of the window ("nibble", iparmq ISPEC = 14) because there the
-    // sweep is the expensive part.  Here the AED is (3 ms of single-wave latency per call), so every AED that leaves an
-    // active block is followed by a sweep in the same iteration: measured 25.0 -> 26.5 solves/s at batch 128, 9.2 -> 12.2 at 16.
-    int nibble = 100;
-    if (const char* e = getenv("TRX_QR_NIBBLE")) {
-        const int v = atoi(e);
-        if (v >= 0 && v <= 100) nibble = v;
-    }
-    int aed_moves = QAED_MOVES;                 // undeflatable eigenvalues moved out of the way per AED (bounded reordering)
-    if (const char* e = getenv("TRX_QR_MOVES")) {
-        const int v = atoi(e);
-        if (v >= 0 && v <= QAED) aed_moves = v;
-    }
-    const bool qr_debug = getenv("TRX_QR_DEBUG") != nullptr;              // cycle breakdown of the prepare kernel (matrix 0) to stderr
-    long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 64);    // 16 counters behind the group summaries
+    // AED window: 64 deflates most per call (fewest sweeps, least slab work) but costs 3 ms of single-wave latency; at small
+    // batches, where nothing is throughput bound, a smaller window shortens the chain
+    const int aed_w = K.aed ? K.aed : (batch >= 64 ? QAED : 48);
+    // LAPACK skips the sweep when AED deflated more than 14 % of the window ("nibble") because there the sweep is the expensive
+    // part.  Here the AED is, so every AED that leaves an active block is followed by a sweep in the same iteration.
+    const int nibble = K.nibble, aed_moves = K.moves;
+    const bool qr_debug = K.debug;                                        // cycle breakdown of the prepare / window kernels (matrix 0) to stderr
+    long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 64);    // 24 counters behind the group summaries
     auto issue_prepare = [&](Group& G) -> bool {
         if (hipMemsetAsync(G.summary, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;      // [3] keeps accumulating
         ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
-        TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.b0 * n * n, n, B.st + G.b0, B.U + (long)G.b0 * QW * QW,
-                   B.shifts + (long)G.b0 * QNS, G.summary, max_sweeps, aed_w, nibble, aed_moves, (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
+        TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.b0 * n * n, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
+                   B.shifts + (long)G.b0 * QKC * QNS, G.summary, max_sweeps, aed_w, nibble, aed_moves, G.par, kc,
+                   (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
         return true;
     };
-    if (qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
     // first prepares are chained (group g starts when group g-1 has finished its own) so that the groups start out of phase
     for (int g = 0; g < ngroups && !rc; ++g) {
-        if (g > 0 && hipStreamWaitEvent(grp[g].s, grp[g - 1].ev, 0) != hipSuccess) rc = TRX_ERR_LAUNCH;
+        if (g > 0 && hipStreamWaitEvent(grp[g].s, grp[g - 1].lane.ev, 0) != hipSuccess) rc = TRX_ERR_LAUNCH;
         if (!rc && !issue_prepare(grp[g])) rc = TRX_ERR_LAUNCH;
-        if (!rc && ngroups > 1 && hipEventRecord(grp[g].ev, grp[g].s) != hipSuccess) rc = TRX_ERR_LAUNCH;
+        if (!rc && ngroups > 1 && hipEventRecord(grp[g].lane.ev, grp[g].s) != hipSuccess) rc = TRX_ERR_LAUNCH;
     }
     int live = rc ? 0 : ngroups;
     for (long visit = 0; live > 0 && visit < (long)ngroups * (64L * n + 1000); ++visit) {
@@ -924,33 +1077,50 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (summary[0] == 0) { G.done = true; --live; continue; }
         cx<T>* Ag = B.A + (long)G.b0 * n * n;
         cx<T>* Zg = B.Z + (long)G.b0 * n * n;
-        cx<T>* Ug = B.U + (long)G.b0 * QW * QW;
-        const cx<T>* shg = B.shifts + (long)G.b0 * QNS;
+        cx<T>* Ug = B.U + (long)G.b0 * QKC * QW * QW;
+        const cx<T>* shg = B.shifts + (long)G.b0 * QKC * QNS;
         QrState* stg = B.st + G.b0;
-        const int nwin = summary[1] > 0 ? cdiv_i(summary[1] + 2 * QNS, adv) + 2 : 1;
+        // window steps of this sweep: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary),
+        // every further chain enters about 3 steps behind the one ahead (blocking rule in qr_window_kernel); a chain that is
+        // still under way after that (flag 2 of the summary) just gets more steps
+        int nwin = 1;
+        if (summary[1] > 0) nwin = cdiv_i(summary[1] + 2 * QNS, adv) + 2 + 4 * (kc - 1);
+        unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              TRX_LAUNCH((qr_window_kernel<T>), dim3(G.nb), dim3(WTHREADS), smw, G.s, Ag, n, stg, Ug, shg, (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
+              TRX_LAUNCH((qr_window_kernel<T>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, n, stg, Ug, shg, G.par, (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
+            G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-              if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1>), dim3(nslabwg, G.nb), dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, (unsigned*)(G.summary + 3));
-              else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2>), dim3(nslabwg, G.nb), dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, (unsigned*)(G.summary + 3));
-              else TRX_LAUNCH((apply_window_kernel<T, 4>), dim3(nslabwg, G.nb), dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, (unsigned*)(G.summary + 3)); }
+              const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(nslabA, G.nb);
+              if (kc == 1) {
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
+              } else if (spw == 1) {
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+              } else if (spw == 2) {
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+              } else {
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+              } }
         }
         if (!issue_prepare(G)) { rc = TRX_ERR_LAUNCH; break; }
     }
     double work = 0;
-    for (int g = 0; g < ngroups; ++g) {
+    for (int g = 0; g < nlanes; ++g) {
         Group& G = grp[g];
         work += G.work;
-        if (g > 0 && G.s) {
-            // join: the caller's stream waits for everything queued on the group's stream; nothing may outlive its stream
-            if (hipEventRecord(G.ev, G.s) != hipSuccess || hipStreamWaitEvent(s, G.ev, 0) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
+        if (g > 0) {
+            // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
+            if (hipEventRecord(G.lane.ev, G.s) != hipSuccess || hipStreamWaitEvent(s, G.lane.ev, 0) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
             if (hipStreamSynchronize(G.s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
-            hipStreamDestroy(G.s);
         }
-        if (G.ev) hipEventDestroy(G.ev);
+        lane_return(G.lane);
     }
-    if (ev_fork) hipEventDestroy(ev_fork);
+    if (ngroups > 1) lane_return(fork);
     if (rc) return rc;
     if (qr_debug) {
         long long h[24];
