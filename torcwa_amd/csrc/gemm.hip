@@ -2,7 +2,7 @@
 // Replaces the torch.matmul call sites of the reference hot path (torcwa/rcwa.py:1161-1164, 1226-1232,
 // 1236, 1260-1281, 1287-1304) and serves every block update of the LU and eigensolver kernels.
 //
-// Kernel: BK = 16, 256 threads = 4 waves arranged WR x (4/WR); a wave owns 16 rows x 16*NT columns (NT MFMA tiles, complex
+// Kernel: K-slab BK = 16 or 32, 256 threads = 4 waves arranged WR x (4/WR); a wave owns 16 rows x 16*NT columns (NT MFMA tiles, complex
 // accumulators).  Three block tiles cover the shapes of the hot path:
 //   <WR=4,NT=4>  64 x 64    the general case
 //   <WR=4,NT=2>  64 x 32    outputs at most 32 columns wide (panel products Z V, A V of the Hessenberg reduction)
@@ -17,24 +17,26 @@
 namespace trx {
 
 namespace {
-constexpr int BK = 16;
-constexpr int LDK = BK + 2;      // k-contiguous plane: element (major, k) at [major*LDK + k]
+// K-slab depth.  32: with the 3M product a 16-deep slab is only 48 MFMAs per wave (~1.3 us), shorter than the latency of the
+// register prefetch of the next slab under load; 32 doubles the distance and halves the barriers per flop (measured below).
 // major-contiguous plane: element (major, k) at [k*ldm + major], ldm = 16 (mod 32) and >= the tile extent
 constexpr int ldm_of(int extent) { return extent <= 64 ? 80 : 144; }
-constexpr int plane_of(int extent) { return (extent * LDK > BK * ldm_of(extent)) ? extent * LDK : BK * ldm_of(extent); }
+// k-contiguous plane: element (major, k) at [major*(BK+2) + k]
+constexpr int plane_of(int extent, bool k_contig, int bk) { return k_contig ? extent * (bk + 2) : bk * ldm_of(extent); }
 
-template <class T, int OPA, int OPB, int WR, int NT>
+template <class T, int OPA, int OPB, int WR, int NT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
                                                         int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
+    constexpr int LDK = BK + 2;
     constexpr int WC = 4 / WR;                   // waves along N
     constexpr int BM = 16 * WR, BN = 16 * NT * WC;
     constexpr int LDMA = ldm_of(BM), LDMB = ldm_of(BN);
-    constexpr int RA = BM / 16, RB = BN / 16;    // elements per thread and slab of the A / B tile
-    __shared__ T Ar[plane_of(BM)];
-    __shared__ T Ai[plane_of(BM)];
-    __shared__ T Br[plane_of(BN)];
-    __shared__ T Bi[plane_of(BN)];
+    constexpr int RA = BM * BK / 256, RB = BN * BK / 256;    // elements per thread and slab of the A / B tile
+    __shared__ T Ar[plane_of(BM, OPA == TRX_OP_N, BK)];
+    __shared__ T Ai[plane_of(BM, OPA == TRX_OP_N, BK)];
+    __shared__ T Br[plane_of(BN, OPB != TRX_OP_N, BK)];
+    __shared__ T Bi[plane_of(BN, OPB != TRX_OP_N, BK)];
     const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
@@ -60,20 +62,22 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
-            const int row = A_KC ? (e >> 4) : (e % BM), kk = A_KC ? (e & 15) : (e / BM);
+            const int row = A_KC ? (e / BK) : (e % BM), kk = A_KC ? (e % BK) : (e / BM);
             const bool ok = (m0 + row < m) && (k0 + kk < k);
             const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            cx<T> v = (OPA == TRX_OP_N) ? A[(long)gr * lda + gk] : A[(long)gk * lda + gr];
+            // 32-bit element offsets from the block-uniform base (scalar base + vector offset addressing: one register per load
+            // instead of two); the host checks that a matrix spans less than 2^31 elements
+            cx<T> v = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
             if (OPA == TRX_OP_C) v.y = -v.y;
             ra[r] = ok ? v : cx<T>(T(0), T(0));
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
-            const int col = B_KC ? (e >> 4) : (e % BN), kk = B_KC ? (e & 15) : (e / BN);
+            const int col = B_KC ? (e / BK) : (e % BN), kk = B_KC ? (e % BK) : (e / BN);
             const bool ok = (n0 + col < n) && (k0 + kk < k);
             const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            cx<T> v = (OPB == TRX_OP_N) ? B[(long)gk * ldb + gc] : B[(long)gc * ldb + gk];
+            cx<T> v = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
             if (OPB == TRX_OP_C) v.y = -v.y;
             rb[r] = ok ? v : cx<T>(T(0), T(0));
         }
@@ -82,22 +86,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
-            const int row = A_KC ? (e >> 4) : (e % BM), ka = A_KC ? (e & 15) : (e / BM);
+            const int row = A_KC ? (e / BK) : (e % BM), ka = A_KC ? (e % BK) : (e / BM);
             Ar[row * sAr + ka * sAk] = ra[r].x; Ai[row * sAr + ka * sAk] = ra[r].y;
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
-            const int col = B_KC ? (e >> 4) : (e % BN), kb = B_KC ? (e & 15) : (e / BN);
+            const int col = B_KC ? (e / BK) : (e % BN), kb = B_KC ? (e % BK) : (e / BN);
             Br[col * sBc + kb * sBk] = rb[r].x; Bi[col * sBc + kb * sBk] = rb[r].y;
         }
     };
 
-    typename Mfma<T>::acc_t accR[NT], accI[NT];
+    // fp64: 3M complex product (P1 = Ar Br, P2 = Ai Bi, P3 = (Ar+Ai)(Br+Bi); see mfma.hpp); fp32: 4M (accR, accI; accX unused)
+    constexpr bool M3 = sizeof(T) == 8;
+    typename Mfma<T>::acc_t accR[NT], accI[NT], accX[M3 ? NT : 1];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); }
+        for (int r = 0; r < 4; ++r) { accR[j][r] = T(0); accI[j][r] = T(0); if (M3) accX[M3 ? j : 0][r] = T(0); }
 
     const int wave = t >> 6, lane = t & 63;
     const int arow0 = 16 * (wave % WR), bcol0 = 16 * NT * (wave / WR);
@@ -108,8 +114,23 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         store_tiles();
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
-        cmma_tile_strided<T, NT>(Ar, Ai, sAr, sAk, arow0, Br, Bi, sBk, sBc, bcol0, BK, accR, accI);
+        // 16 k-values at a time: bounds the unrolled fragment prefetch (a 32-deep unroll spills)
+#pragma unroll 1
+        for (int kh = 0; kh < BK; kh += 16) {
+            if constexpr (M3) cmma3_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI, accX);
+            else cmma_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI);
+        }
         __syncthreads();
+    }
+    if constexpr (M3) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T p1 = accR[j][r], p2 = accI[j][r];
+                accR[j][r] = p1 - p2;                       // Cr = Ar Br - Ai Bi
+                accI[j][r] = accX[j][r] - p1 - p2;          // Ci = (Ar+Ai)(Br+Bi) - Ar Br - Ai Bi
+            }
     }
     // C tile of this lane (beta != 0): all loads are issued back to back with clamped addresses (the guards sit at the
     // store), so a rank-32/64 update pays the read latency of C once instead of once per element behind an exec branch.
@@ -144,12 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
 template <class T, int OPA, int OPB>
 void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
                   const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
+    // K-slab depth 16 everywhere.  A 32-deep slab for the general tile (half the barriers per flop, twice the prefetch distance) was
+    // measured SLOWER on MI355X with the 3M product (70.9 vs 72.6 TF at 1922^3 x 128: 256 VGPRs, one spill); the template keeps it.
     if (shape == 1)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else if (shape == 2)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
 }
 
 template <class T, int OPA>
@@ -171,6 +194,10 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
          const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, int batch, const GemmDesc* desc, int b_upper) {
     if (m <= 0 || n <= 0 || batch <= 0) return TRX_OK;
     if (k <= 0 && !desc) return TRX_ERR_ARG;          // callers never pass an empty inner dimension
+    {   // operand tiles are addressed with 32-bit element offsets inside one matrix
+        const long ra = (opA == TRX_OP_N ? m : k), rb = (opB == TRX_OP_N ? k : n);
+        if (ra * lda >= 2147483647L || rb * ldb >= 2147483647L || (long)m * ldc >= 2147483647L) return TRX_ERR_UNSUPPORTED;
+    }
     // block-tile shape: 64x32 for narrow outputs, 32x128 for flat ones (per-batch descriptors keep the general tile: their
     // sizes are only known on the device)
     const int shape = desc ? 0 : (n <= 32 ? 1 : (m <= 32 ? 2 : 0));

@@ -66,4 +66,39 @@ __device__ __forceinline__ void cmma_tile_strided(const T* __restrict__ Ar, cons
     }
 }
 
+// Same tile with the 3M complex product (three real MFMAs per k-step instead of four):
+//   P1 += Ar Br,  P2 += Ai Bi,  P3 += (Ar + Ai)(Br + Bi);      Cr = P1 - P2,  Ci = P3 - P1 - P2   (cmma3_finish)
+// The operand sums are formed in registers (one VALU add per fragment, co-issued with the matrix pipe), so LDS traffic and
+// layout are those of the 4M tile and the matrix-core work drops by a quarter.  Normwise the error bound is the 4M one
+// (eps * (|Ar|+|Ai|)(|Br|+|Bi|) per term); only the RELATIVE accuracy of an imaginary part much smaller than its real part
+// is weaker, which the S-matrix algebra never relies on.  Used for the fp64 path (the c128 parity gate, 1e-9, is held with it:
+// tests/test_blocks.py, test_pipeline.py); the fp32 path keeps 4M, its budget being the tighter one.
+template <class T, int NT>
+__device__ __forceinline__ void cmma3_tile_strided(const T* __restrict__ Ar, const T* __restrict__ Ai, int sAr, int sAk, int arow0,
+                                                   const T* __restrict__ Br, const T* __restrict__ Bi, int sBk, int sBc, int bcol0, int kcount,
+                                                   typename Mfma<T>::acc_t (&p1)[NT], typename Mfma<T>::acc_t (&p2)[NT], typename Mfma<T>::acc_t (&p3)[NT]) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int aoff = (arow0 + lr) * sAr + lk * sAk;
+    const int boff = lk * sBk + (bcol0 + lr) * sBc;
+    for (int k0 = 0; k0 < kcount; k0 += 4) {
+        const T ar = Ar[aoff + k0 * sAk];
+        const T ai = Ai[aoff + k0 * sAk];
+        const T as = ar + ai;
+        T br[NT], bi[NT], bs[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            br[j] = Br[boff + k0 * sBk + 16 * j * sBc];
+            bi[j] = Bi[boff + k0 * sBk + 16 * j * sBc];
+            bs[j] = br[j] + bi[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) p1[j] = Mfma<T>::mma(ar, br[j], p1[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) p2[j] = Mfma<T>::mma(ai, bi[j], p2[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) p3[j] = Mfma<T>::mma(as, bs[j], p3[j]);
+    }
+}
+
 }  // namespace trx
