@@ -804,12 +804,98 @@ __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, con
 // workgroups (8 waves) resident on a CU run out of phase, so one wave's load latency hides behind the MFMAs of its SIMD
 // neighbour (an explicit register double-buffer pushes the kernel over 256 VGPRs and the spill reloads, which share the
 // vector-memory counter with the prefetch, then serialise everything -- measured on the ISA).
+// 3M variant of one K half for the tile pair (2 pp, 2 pp + 1): three real MFMAs per k-step and tile (mfma.hpp).
+//   right update (C = X U):    P1 += xr ur,  P2 += xi ui,  P3 += (xr + xi)(ur + ui);   Cr = P1 - P2,  Ci = P3 - P1 - P2
+//   left update  (C = U^H X):  P1 += ur xr,  P2 += ui xi,  P3 += (ur - ui)(xr + xi);   Cr = P1 + P2,  Ci = P3 - P1 + P2
+template <class T, int SIDE>
+__device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int pp, int lane, const cx<T> (&x)[8],
+                                                      typename Mfma<T>::acc_t (&p1)[2], typename Mfma<T>::acc_t (&p2)[2], typename Mfma<T>::acc_t (&p3)[2]) {
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (16 * (2 * h + cc) + 4 * lk + j) * MLD + lr + 32 * pp;
+            const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
+            const T xs = xr + xi;
+            T ur[2], ui[2], us[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
+                us[q] = SIDE == 1 ? ur[q] + ui[q] : ur[q] - ui[q];
+            }
+            if (SIDE == 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(xr, ur[q], p1[q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(xi, ui[q], p2[q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(xs, us[q], p3[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(ur[q], xr, p1[q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(ui[q], xi, p2[q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
+            }
+        }
+}
+
+template <class T>
+__device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, int w0, int ww, int lane, int pp, const typename Mfma<T>::acc_t (&accR)[2],
+                                                const typename Mfma<T>::acc_t (&accI)[2]) {
+    const int lr = lane & 15;
+    char* base = reinterpret_cast<char*>(d.X);       // scalar base + 32-bit byte offsets, as in slab_load_half
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cr = Mfma<T>::crow(lane, r);
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int q = 2 * pp + q2;
+            const cx<T> v(accR[q2][r], accI[q2][r]);
+            if (d.side == 1) {
+                const int row = d.a0 + cr, k = 16 * q + lr;
+                if (row < d.lim && k < ww) *reinterpret_cast<cx<T>*>(base + ((unsigned)row * n + w0 + k) * (unsigned)sizeof(cx<T>)) = v;
+            } else {
+                const int i = 16 * q + cr, col = d.a0 + lr;
+                if (i < ww && col < d.lim) *reinterpret_cast<cx<T>*>(base + ((unsigned)(w0 + i) * n + col) * (unsigned)sizeof(cx<T>)) = v;
+            }
+        }
+    }
+}
+
 template <class T, int SIDE>
 __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane) {
     cx<T> xa[8], xb[8];
     slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
     slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
+    if constexpr (sizeof(T) == 8) {
+        // fp64: 3M product, two of the four output tiles at a time (the streamed operand stays in registers for both passes, the
+        // U fragments of the second pass are other columns of the same LDS planes): 48 accumulator registers instead of 64, a
+        // quarter fewer MFMAs -- the update sits at the HBM / matrix-core balance point, so this moves it onto the HBM side
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            typename Mfma<T>::acc_t p1[2], p2[2], p3[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p1[q][r] = T(0); p2[q][r] = T(0); p3[q][r] = T(0); }
+            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 0, pp, lane, xa, p1, p2, p3);
+            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 1, pp, lane, xb, p1, p2, p3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const T a = p1[q][r], b = p2[q][r], c = p3[q][r];
+                    p1[q][r] = SIDE == 1 ? a - b : a + b;               // real part
+                    p2[q][r] = SIDE == 1 ? c - a - b : c - a + b;       // imaginary part
+                }
+            slab_store_pair<T>(d, n, w0, ww, lane, pp, p1, p2);
+        }
+        return;
+    }
     typename Mfma<T>::acc_t accR[4], accI[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
