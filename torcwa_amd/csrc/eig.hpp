@@ -26,7 +26,7 @@ struct QrState {
     int stall, sweeps;
     int w0[EigPlan::QKC], w1[EigPlan::QKC];   // window of each chain's last step: its pending off-window update acts on [w0, w1)
     int fail;                     // number of unconverged eigenvalues on failure
-    int pad;
+    int strip_next;               // next unclaimed strip of the pending off-window update (dynamic strip scheduling; reset per window step)
 };
 enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
 

@@ -276,7 +276,7 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_init_kernel(QrState* __restrict__ st, int n) {
     if (threadIdx.x == 0) {
         QrState s;
-        s.ilo = 0; s.ihi = n - 1; s.nch = 0; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0; s.fail = 0; s.pad = 0;
+        s.ilo = 0; s.ihi = n - 1; s.nch = 0; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0; s.fail = 0; s.strip_next = 0;
         for (int c = 0; c < QKC; ++c) { s.k[c] = 0; s.tau[c][0] = s.tau[c][1] = 1; s.tau_last[c] = 0; s.w0[c] = 0; s.w1[c] = 0; }
         st[blockIdx.x] = s;
     }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     cx<T>* Uw = Hw + QW * LD;                          // [QW][LD]
     QrState& sst = *reinterpret_cast<QrState*>(Uw + QW * LD);
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
-    if (t == 0) sst = st_all[b];
+    if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
     __syncthreads();
     const QrState st = sst;
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
@@ -937,9 +937,13 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 // SPW = strips per wave (a workgroup covers 4*SPW strips): 1 gives the shortest dependent chain per launch and the most
 // workgroups (what matters when several iteration groups keep the GPU busy with small launches); larger values amortise the
 // U prologue (64 KiB from L2 per workgroup) over more streamed data.
+// PART 2 claims its strips DYNAMICALLY (per-matrix counter QrState::strip_next, reset by the window kernel of the step): the
+// latency-bound kernels of the other iteration groups hold whole CUs (133 KB of LDS each), so a launch sized to fill the chip
+// exactly would otherwise run a second, nearly empty round of workgroups on the CUs that are left; with dynamic claiming a
+// workgroup that starts late finds the counter exhausted and leaves, and the launch ends when the work does.
 template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n,
-                                                           const QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
+                                                           QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
                                                            unsigned* __restrict__ work, int nslab) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
@@ -952,7 +956,8 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
     const int S = PART == 0 ? nL : (PART == 1 ? nR + nZ : nL + nR + nZ);
     const int g0 = gx * (4 * SPW);
-    if (g0 >= S) return;
+    if (PART == 2) { if (*(volatile int*)&st_all[b].strip_next >= S) return; }
+    else if (g0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
     if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
@@ -967,8 +972,13 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     __syncthreads();
     cx<T>* H = Aall + (long)b * n * n;
     cx<T>* Z = Zall + (long)b * n * n;
-    for (int i = 0; i < SPW; ++i) {
-        const int g = g0 + wave + 4 * i;
+    for (int i = 0; PART == 2 || i < SPW; ++i) {
+        int g = g0 + wave + 4 * i;
+        if (PART == 2) {
+            g = 0;
+            if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
+            g = __builtin_amdgcn_readfirstlane(g);
+        }
         if (g >= S) break;
         const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
         if (PART == 0 || (PART == 2 && d.side == 0)) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
@@ -1081,7 +1091,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const int nslabL = cdiv_i(nstrip + 1, 4 * spw);          // workgroups per matrix and chain: left strips <= n/16 + 1
     const int nslabR = cdiv_i(2 * nstrip + 1, 4 * spw);      // right-H strips <= n/16 + 1, Z strips = n/16
     const int adv = QW - 2 * QNS - 1;                        // guaranteed chain advance per window step
-    const int nslabA = cdiv_i(2 * nstrip + 2, 4 * spw);      // single-launch variant: all strips of one chain
     // Bulge chains per sweep.  Measured on MI355X (n = 1922): 2 / 3 chains cut the outer iterations by only 31 / 36 % (the AED's
     // deflation yield, not the shift count, paces the iteration) while the slab work grows by a third, and the two-launch
     // update they need costs 10 % on its own: 26.5 (1 chain, one launch) vs 22.1 / 21.9 solves/s at batch 128, 12.1 vs 11.3 at
@@ -1177,20 +1186,25 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               TRX_LAUNCH((qr_window_kernel<T>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, n, stg, Ug, shg, G.par, (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-              const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(nslabA, G.nb);
+              // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
+              // (about two workgroups per CU over the group), whatever the group size
+              int wgm = 512 / G.nb;
+              wgm = wgm < 8 ? 8 : (wgm > 32 ? 32 : wgm);          // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
+              if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
+              const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(wgm, G.nb);
               if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabA);
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, (const QrState*)stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
               } }
         }
         if (!issue_prepare(G)) { rc = TRX_ERR_LAUNCH; break; }
