@@ -102,8 +102,11 @@ int trx_build_pq(int dtype, const void* E, const void* Einv, const void* Mu, con
  *         phase [batch,n] = exp(i*omega*kz*thickness) (rcwa.py:1246).
  * Outputs S11, S21 [batch,n,n] (the layer's S22 == S11 and S12 == S21 identically), V [batch,n,n] (H_eigvec),
  *         optional Cplus, Cminus [batch,n,n]: Cf = [Cplus; Cminus], Cb = [Cminus; Cplus] (rcwa.py:1271-1274).
- * piv: int[3*batch*n], info: int[3*batch] (slot 0..B-1: P factorisation; B..3B-1: the two n x n inverses). */
+ * piv: int[3*batch*n], info: int[3*batch] (slot 0..B-1: P factorisation; B..3B-1: the two n x n inverses).
+ * Workspace: trx_layer_smatrix_ws_bytes (6 matrices per point); when Cplus == NULL and S11 | S21 are ONE contiguous
+ * [2*batch,n,n] block (S21 == S11 + batch*n*n) the outputs double as scratch and trx_layer_smatrix_ws_bytes_lean (4) suffices. */
 size_t trx_layer_smatrix_ws_bytes(int dtype, int N, int batch);
+size_t trx_layer_smatrix_ws_bytes_lean(int dtype, int N, int batch);
 /* H-field modes V = P^-1 W diag(kz) (rcwa.py:1248, 1264) of a layer with HOMOGENEOUS mu, from the rank-N structure
  * P = mu J + [Kx; Ky] E^-1 [Ky, -Kx] (rcwa.py:1226-1228): one N x N factorisation of E - (Kx^2 + Ky^2)/mu and a 2N-column
  * solve replace the LU of the 2N x 2N matrix P (0.29 n^3 instead of 1.33 n^3 complex MACs).  E [batch,N,N] permittivity

@@ -27,6 +27,7 @@ _SIGS = {
     "trx_eig_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_build_pq": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "trx_layer_smatrix_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "trx_layer_smatrix_ws_bytes_lean": (c_size_t, [c_int, c_int, c_int]),
     "trx_layer_smatrix": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_eig_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

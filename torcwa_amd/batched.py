@@ -196,8 +196,15 @@ class BatchedRCWA:
         if eps_h and mu_h and not diff and not self.keep_coupling:
             self._add_homogeneous_layer_bd(thickness, self._bvec(eps), self._bvec(mu))
             return
+        # Sweep drivers (keep_coupling=False) with a homogeneous mu never read P, Q, the dense mu matrices or, after the layer's
+        # S-matrix, the mode matrices W, V: A = PQ and V = P^-1 W Kz come from E directly (trx_build_a / trx_hmodes).  Not building
+        # / not keeping them takes 4 of ~16 n^2-sized tensors per sweep point out of the peak.
+        lean = (not diff) and (not self.keep_coupling) and mu_h and (not eps_h) and (not self.avoid_Pinv_instability)
         E, Einv, eps_s = conv(eps, eps_h)
-        M, Minv, mu_s = conv(mu, mu_h)
+        if lean:
+            M, Minv, mu_s = None, None, self._bvec(mu)
+        else:
+            M, Minv, mu_s = conv(mu, mu_h)
         self.eps_conv.append(E)
         self.mu_conv.append(M)
         self.layer_N += 1
@@ -207,10 +214,12 @@ class BatchedRCWA:
         inv = (lambda A: ag.InverseFn.apply(A, eng)) if diff else eng.inverse
         if Einv is None:
             Einv = inv(E)
-        if Minv is None:
+        if Minv is None and M is not None:
             Minv = inv(M)
         if diff:
             P, Q = self._pq_torch(E, Einv, M, Minv, kxd, kyd)
+        elif lean:
+            P = Q = None
         else:
             P, Q = eng.build_pq(E, Einv, M, Minv, kxd, kyd)
         if eps_h and mu_h:                                                              # rcwa.py:1206-1222
@@ -228,6 +237,7 @@ class BatchedRCWA:
             else:
                 # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
                 A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
+                del Einv
                 lam, W = eng.eig(A, destroy=True)                                       # torch_eig.py:14
                 del A
             kz = torch.sqrt(lam)
@@ -366,6 +376,9 @@ class BatchedRCWA:
                 S11, S21, V = torch.where(sel, alt[0], S11), torch.where(sel, alt[1], S21), torch.where(sel, alt[2], V)
                 if self.keep_coupling:
                     cp, cm = torch.where(sel, alt[3], cp), torch.where(sel, alt[4], cm)
+        if not self.keep_coupling and not self.avoid_Pinv_instability and self._mu_scalar is not None:
+            self.E_eigvec[-1] = None          # sweep drivers: the mode matrices are not read again (see add_layer)
+            V = None
         self.H_eigvec.append(V)
         self.layer_S11.append(S11)
         self.layer_S21.append(S21)

@@ -944,7 +944,7 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n,
                                                            QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work, int nslab) {
+                                                           unsigned* __restrict__ work, int nslab, int dynamic) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
     const int S = PART == 0 ? nL : (PART == 1 ? nR + nZ : nL + nR + nZ);
     const int g0 = gx * (4 * SPW);
-    if (PART == 2) { if (*(volatile int*)&st_all[b].strip_next >= S) return; }
+    if (PART == 2 && dynamic) { if (*(volatile int*)&st_all[b].strip_next >= S) return; }
     else if (g0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
@@ -972,13 +972,26 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     __syncthreads();
     cx<T>* H = Aall + (long)b * n * n;
     cx<T>* Z = Zall + (long)b * n * n;
-    for (int i = 0; PART == 2 || i < SPW; ++i) {
-        int g = g0 + wave + 4 * i;
-        if (PART == 2) {
-            g = 0;
+    if (PART == 2 && dynamic) {
+        // dynamic claiming; the next claim is issued before the current strip is processed, so that the round trip of the atomic
+        // (1-2 us) hides behind a strip's worth of loads and MFMAs (a wave over-claims once at the end: harmless)
+        auto claim = [&]() {
+            int g = 0;
             if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
-            g = __builtin_amdgcn_readfirstlane(g);
+            return __builtin_amdgcn_readfirstlane(g);
+        };
+        int g = claim();
+        while (g < S) {
+            const int gn = claim();
+            const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
+            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            g = gn;
         }
+        return;
+    }
+    for (int i = 0; i < SPW; ++i) {
+        const int g = g0 + wave + 4 * i;
         if (g >= S) break;
         const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
         if (PART == 0 || (PART == 2 && d.side == 0)) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
@@ -1188,23 +1201,28 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
               // (about two workgroups per CU over the group), whatever the group size
-              int wgm = 512 / G.nb;
-              wgm = wgm < 8 ? 8 : (wgm > 32 ? 32 : wgm);          // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
-              if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
+              // (groups of fewer than 16 matrices are latency bound and nothing competes for their CUs: static strips, measured faster)
+              const int dyn = G.nb >= 16;
+              int wgm = cdiv_i(2 * nstrip + 2, 4 * spw);
+              if (dyn) {
+                  wgm = 512 / G.nb;
+                  wgm = wgm < 8 ? 8 : (wgm > 32 ? 32 : wgm);      // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
+                  if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
+              }
               const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(wgm, G.nb);
               if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm);
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } }
         }
         if (!issue_prepare(G)) { rc = TRX_ERR_LAUNCH; break; }

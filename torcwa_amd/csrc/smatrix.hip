@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void layer_G_kernel(const cx<T>* __restrict__ 
 
 // S11 = Mp - Mm,  S21 = Mp + Mm - I
 template <class T>
-__global__ __launch_bounds__(256) void layer_S_kernel(const cx<T>* __restrict__ Mp, const cx<T>* __restrict__ Mm, int n, cx<T>* __restrict__ S11, cx<T>* __restrict__ S21) {
+__global__ __launch_bounds__(256) void layer_S_kernel(const cx<T>* Mp, const cx<T>* Mm, int n, cx<T>* S11, cx<T>* S21) {      // may run in place (S11 == Mp, S21 == Mm)
     const int b = blockIdx.z, i = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -228,7 +228,9 @@ int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* 
     const dim3 g(cdiv_i(n, 256), n, batch), blk(256);
     cx<T>* T2 = ws;              // [2B, n, n]: Tp | Tm, inverted in place
     cx<T>* G = ws + 2 * bn;      // [2B, n, n]: scratch (LU copy of P / inverse workspace / G1 | G2)
-    cx<T>* Mx = ws + 4 * bn;     // [2B, n, n]: Mp | Mm
+    // [2B, n, n]: Mp | Mm.  Without coupling coefficients the last step (layer_S_kernel) is elementwise, so when the caller's
+    // S11 | S21 are one contiguous [2B,n,n] block they serve as this buffer and the workspace is 4 instead of 6 matrices per point
+    cx<T>* Mx = (!cp && S21 == S11 + bn) ? S11 : ws + 4 * bn;
     int rc;
     if (use_q == 2) {
         // V supplied by the caller (trx_hmodes)
@@ -383,9 +385,12 @@ int redheffer_halfspace_t(hipStream_t s, int side, const cx<T>* bd, const cx<T>*
         //   S11 = T1 D11,   S12 = Sn12 + T1 M,   S21 = D21 + D22 T2 D11,   S22 = D22 (Sn22 + T2 M)
         // (push-through: (I - Sn21 D12)^-1 = I + T2 D12).  One LU, one 2n-column solve, two n^3 products = 4.33 n^3 complex MACs
         // instead of 6.33; every other step is an O(n^2) combination with block-diagonal factors or a tiled transpose.
-        cx<T>* Kt = ws + bn;           // [B,n,n]
-        cx<T>* Xs = ws + 2 * bn;       // [B,n,2n]  [Sn11^T | Sn21^T] -> solution; later two [B,n,n] temporaries
-        cx<T>* Ys = ws + 4 * bn;       // [B,n,2n]  [T1 | T2]
+        // Scratch that dies before its host is written lives in the OUTPUT blocks (K in S12's, K^T and later M in S22's), so the
+        // workspace is the two [B,n,2n] solve buffers only: 4 instead of 6 matrices per point.
+        K = O[2];
+        cx<T>* Kt = O[3];              // [B,n,n]
+        cx<T>* Xs = ws;                // [B,n,2n]  [Sn11^T | Sn21^T] -> solution; later two [B,n,n] temporaries
+        cx<T>* Ys = ws + 2 * bn;       // [B,n,2n]  [T1 | T2]
         const dim3 tg(cdiv_i(n, 32), cdiv_i(n, 32), batch), tb(32, 8);
         TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[1], n, nn, (const cx<T>*)nullptr, 0, 0L, K, n, nn, N, n, T(-1), 1);
         TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)K, n, nn, Kt, n, nn, n);
@@ -395,7 +400,7 @@ int redheffer_halfspace_t(hipStream_t s, int side, const cx<T>* bd, const cx<T>*
         rc = lu_solve<T>(s, Kt, n, nn, n, piv, Xs, 2 * n, 2 * nn, 2 * n, batch); if (rc) return rc;
         TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Xs, 2 * n, 2 * nn, Ys, 2 * n, 2 * nn, n);
         TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)(Xs + n), 2 * n, 2 * nn, Ys + n, 2 * n, 2 * nn, n);
-        cx<T>* M = K;                  // K is no longer needed (its transpose was factored)
+        cx<T>* M = Kt;                 // the factors of K^T are no longer needed after the solve (and S22, their host, is written last)
         cx<T>* Ta = Xs;                // [B,n,n] temporaries in the solve buffer
         cx<T>* Tb = Xs + bn;
         TRX_LAUNCH((bd_rowcomb_kernel<T>), gN, blk, 0, s, D12, bN, S[3], n, nn, (const cx<T>*)nullptr, 0, 0L, M, n, nn, N, n, T(1), 0);
@@ -517,6 +522,9 @@ extern "C" int trx_build_pq(int dtype, const void* E, const void* Einv, const vo
 extern "C" size_t trx_layer_smatrix_ws_bytes(int dtype, int N, int batch) {
     return (size_t)(dtype == TRX_C128 ? 16 : 8) * 6 * (size_t)batch * (2 * (size_t)N) * (2 * (size_t)N);
 }
+extern "C" size_t trx_layer_smatrix_ws_bytes_lean(int dtype, int N, int batch) {
+    return (size_t)(dtype == TRX_C128 ? 16 : 8) * 4 * (size_t)batch * (2 * (size_t)N) * (2 * (size_t)N);
+}
 
 extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const void* W, const void* kzfac, const void* vfinv,
                                  const void* phase, int use_q, int N, int batch, void* S11, void* S21, void* V, void* Cplus,
@@ -524,7 +532,11 @@ extern "C" int trx_layer_smatrix(int dtype, const void* P, const void* Q, const 
     if (!W || !kzfac || !vfinv || !phase || !S11 || !S21 || !V || !piv || !info || !ws || N <= 0 || batch <= 0) return TRX_ERR_ARG;
     if (use_q < 0 || use_q > 2 || (use_q == 1 && !Q) || (use_q == 0 && !P)) return TRX_ERR_ARG;
     if ((Cplus == nullptr) != (Cminus == nullptr)) return TRX_ERR_ARG;
-    if (ws_bytes < trx_layer_smatrix_ws_bytes(dtype, N, batch)) return TRX_ERR_WORKSPACE;
+    {
+        const size_t esz = dtype == TRX_C128 ? 16 : 8, blk = esz * (size_t)batch * (2 * (size_t)N) * (2 * (size_t)N);
+        const bool lean = !Cplus && (char*)S21 == (char*)S11 + blk;       // outputs double as the last scratch block
+        if (ws_bytes < (lean ? trx_layer_smatrix_ws_bytes_lean(dtype, N, batch) : trx_layer_smatrix_ws_bytes(dtype, N, batch))) return TRX_ERR_WORKSPACE;
+    }
     hipStream_t s = trx::api_stream(stream);
     if (dtype == TRX_C64)
         return layer_smatrix_t<float>(s, (const cx<float>*)P, (const cx<float>*)Q, (const cx<float>*)W, (const cx<float>*)kzfac, (const cx<float>*)vfinv,
@@ -573,7 +585,7 @@ extern "C" int trx_redheffer(int dtype, const void* const* Sm, const void* const
 
 extern "C" size_t trx_redheffer_halfspace_ws_bytes(int dtype, int N, int batch, int side, int want_xy) {
     const size_t nn = (size_t)(dtype == TRX_C128 ? 16 : 8) * (size_t)batch * (size_t)(2 * N) * (size_t)(2 * N);
-    return (side == 0 && !want_xy) ? 6 * nn : nn;
+    return (side == 0 && !want_xy) ? 4 * nn : nn;
 }
 
 extern "C" int trx_redheffer_halfspace(int dtype, int side, const void* bd, const void* const* S, void* const* Sout, void* XY, int N, int batch,

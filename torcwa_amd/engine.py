@@ -202,8 +202,8 @@ class Engine:
         B, n, _ = W.shape
         N = n // 2
         dt = W.dtype
-        S11 = torch.empty((B, n, n), dtype=dt, device=self.device)
-        S21 = torch.empty_like(S11)
+        S = torch.empty((2, B, n, n), dtype=dt, device=self.device)     # S11 | S21 contiguous: without coupling coefficients they double
+        S11, S21 = S[0], S[1]                                           # as the kernel's last scratch block (include/trx.h)
         if V is not None:
             V, use_q = self._c(V), 2
         else:
@@ -211,7 +211,7 @@ class Engine:
         cp = torch.empty_like(S11) if want_c else None
         cm = torch.empty_like(S11) if want_c else None
         piv, info = self._ints(3 * B * n), self._ints(3 * B)
-        nws = self.lib.layer_smatrix_ws_bytes(_CODE[dt], N, B)
+        nws = (self.lib.layer_smatrix_ws_bytes if want_c else self.lib.layer_smatrix_ws_bytes_lean)(_CODE[dt], N, B)
         ws = self._ws(nws)
         W, kzfac, vfinv, phase = self._c(W), self._c(kzfac), self._c(vfinv), self._c(phase)
         self.lib.check(self.lib.layer_smatrix(
