@@ -333,6 +333,8 @@ def main():
         if profile:
             engine.lib.prof_reset()
             engine.lib.prof_enable(1)
+            if not EMU:
+                mstat["timed0"] = torch.cuda.memory_stats(device)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = run_step(freq, grids, order, engine, args, chunk)
@@ -354,6 +356,7 @@ def main():
         idx = local_block(total)
         if scaling == "weak":
             total, idx = args.points * world, np.arange(rank * args.points, (rank + 1) * args.points)
+    mstat = {}
     ms0 = torch.cuda.memory_stats(device) if not EMU else {}
     elapsed, out, (freq, grids, lam, eps_si, chunk) = measure(idx, args.steps, args.warmup, profile=True)
     ms1 = torch.cuda.memory_stats(device) if not EMU else {}
@@ -389,7 +392,10 @@ def main():
         mem = None
         if not EMU:
             mem = {"peak_reserved_GB": ms1.get("reserved_bytes.all.peak", 0) / 1e9, "peak_allocated_GB": ms1.get("allocated_bytes.all.peak", 0) / 1e9,
-                   "device_mallocs_in_run": ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0), "alloc_retries": ms1.get("num_alloc_retries", 0)}
+                   "device_mallocs_in_run": ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0),
+                   "device_mallocs_in_timed_region": ms1.get("segment.all.allocated", 0) - mstat["timed0"].get("segment.all.allocated", 0),
+                   "device_frees_in_timed_region": ms1.get("segment.all.freed", 0) - mstat["timed0"].get("segment.all.freed", 0),
+                   "alloc_retries": ms1.get("num_alloc_retries", 0)}
         wl = ("configs[1]: single patterned layer, order=[%d,%d] (n=%d), %dx%d grid, %d-lambda sweep, glass input half-space"
               % (args.order, args.order, n, args.grid, args.grid, args.batch)) if args.config == 2 else \
              ("configs[3]: Example3-style (Wx,Wy,lambda) sweep, %d independent single-layer solves, order=[%d,%d] (n=%d), %dx%d grid, sharded by contiguous blocks"

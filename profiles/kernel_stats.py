@@ -130,8 +130,82 @@ def gaps(path, top=25, min_us=50.0, from_ms=0.0):
         print(f"{a[0]:7d} {a[1] / 1e6:9.1f}  {k[0]} -> {k[1]}")
 
 
+def concurrency(path, pattern="qr_|apply_window"):
+    """Time-weighted histogram of the number of kernels running at once while at least one kernel matching `pattern` runs, the
+    same per stream/queue, and the in-stream gap between consecutive kernels of one stream (launch latency the GPU sees)."""
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.cursor().execute("pragma table_info(kernels)")]
+    qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+    q = f"select name, start, end, {qcol if qcol else '0'} from kernels"
+    rows = sorted((a, b, short(nm), sid) for nm, a, b, sid in con.cursor().execute(q))
+    pat = re.compile(pattern)
+    sel = [r for r in rows if pat.search(r[2])]
+    t_lo, t_hi = sel[0][0], max(r[1] for r in sel)
+    ev = []
+    for a, b, nm, sid in rows:
+        if b < t_lo or a > t_hi:
+            continue
+        ev.append((a, 1, nm))
+        ev.append((b, -1, nm))
+    ev.sort()
+    hist, cur, last = {}, 0, ev[0][0]
+    by_kind = {}
+    active = {}
+    for tme, d, nm in ev:
+        hist[cur] = hist.get(cur, 0) + (tme - last)
+        key = tuple(sorted(k for k, v in active.items() if v > 0))
+        by_kind[key] = by_kind.get(key, 0) + (tme - last)
+        last = tme
+        cur += d
+        active[nm.split("<")[0]] = active.get(nm.split("<")[0], 0) + d
+    tot = sum(hist.values())
+    print(f"# {path}: QR-phase window {(t_hi - t_lo) / 1e6:.1f} ms; stream column: {qcol}")
+    print("concurrent kernels : share of time")
+    for k in sorted(hist):
+        print(f"   {k:2d} : {100 * hist[k] / tot:5.1f}%")
+    print("kernel kinds running together (top 12):")
+    for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"   {100 * v / tot:5.1f}%  {' + '.join(k) if k else '(idle)'}")
+    if qcol:
+        per = {}
+        for a, b, nm, sid in rows:
+            if a < t_lo or a > t_hi:
+                continue
+            per.setdefault(sid, []).append((a, b, nm))
+        print("per stream: kernels, busy ms, in-stream gap (median / mean us)")
+        for sid, lst in sorted(per.items()):
+            gaps_ = [lst[i + 1][0] - lst[i][1] for i in range(len(lst) - 1)]
+            gaps_ = [g for g in gaps_ if g < 5e6]
+            busy = sum(b - a for a, b, _ in lst)
+            if gaps_:
+                gs = sorted(gaps_)
+                print(f"   stream {sid}: {len(lst)} kernels, busy {busy / 1e6:.1f} ms, gap median {gs[len(gs) // 2] / 1e3:.1f} us, mean {sum(gs) / len(gs) / 1e3:.1f} us")
+
+
+def excerpt(path, at_frac=0.55, span_us=1500.0):
+    """Raw timeline excerpt: every kernel that runs within span_us after the point at_frac of the trace (stream, start, duration)."""
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.cursor().execute("pragma table_info(kernels)")]
+    qcol = "stream_id" if "stream_id" in cols else "0"
+    rows = sorted((a, b, short(nm), sid, gx // max(wx, 1), gy // max(wy, 1)) for nm, a, b, sid, gx, gy, wx, wy in
+                  con.cursor().execute(f"select name, start, end, {qcol}, grid_x, grid_y, workgroup_x, workgroup_y from kernels"))
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    # start the excerpt at an apply_window kernel near at_frac
+    lo = t0 + at_frac * (t1 - t0)
+    cand = [r for r in rows if r[0] >= lo and "apply_window" in r[2]]
+    lo = cand[0][0] if cand else lo
+    print(f"# timeline excerpt, {span_us:.0f} us from t = {(lo - t0) / 1e6:.1f} ms; columns: stream  start_us  dur_us  kernel  grid")
+    for a, b, nm, sid, gx, gy in rows:
+        if b >= lo and a <= lo + span_us * 1e3:
+            print(f"  s{sid}  {(a - lo) / 1e3:9.1f}  {(b - a) / 1e3:8.1f}  {nm.split('<')[0]:24s} ({gx},{gy})")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+    if len(sys.argv) > 2 and sys.argv[2] == "--excerpt":
+        excerpt(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else 0.55)
+    elif len(sys.argv) > 2 and sys.argv[2] == "--concurrency":
+        concurrency(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "--gaps":
         gaps(sys.argv[1], from_ms=float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
     elif len(sys.argv) > 2 and sys.argv[2] == "--phases":
         phases(sys.argv[1])

@@ -39,6 +39,8 @@ inline hipError_t hipPeekAtLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static const unsigned hipHostMallocDefault = 0;
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 2; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
@@ -51,6 +53,8 @@ typedef void* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static const hipError_t hipErrorNotReady = 600;
+inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 // streams execute synchronously in the emulator: extra streams and cross-stream waits are no-ops
 static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;

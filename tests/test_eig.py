@@ -137,6 +137,24 @@ def test_eig_tuning_knobs(backend, knobs):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("pipe", [2, 1])
+def test_eig_pipelined_slab_kernel(backend, pipe):
+    """The software-pipelined off-window update (fp64, n >= 128, dynamically claimed strips; full-width window frames with identity
+    padding, shifted up at the bottom of the matrix) against the one-strip-at-a-time kernel: same results.  slab_dyn = 2 forces the
+    dynamic path for this small batch; slab_pipe = 2 selects the pipelined kernel, 1 the default one."""
+    be = get_backend(backend)
+    n = 140 if backend == "emu" else 333
+    A = (RNG.standard_normal((3, n, n)) + 1j * RNG.standard_normal((3, n, n))).astype(np.complex128)
+    A[2] = 0.2 * A[2] + np.diag(np.linspace(-9, 9, n)).astype(np.complex128)
+    try:
+        _set_knobs(be, slab_dyn=2, slab_pipe=pipe)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, slab_dyn=0, slab_pipe=0)
+    check(A, w, V, info, 1e-12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("chains", [3, 2, 1])
 def test_eig_multiple_bulge_chains(backend, chains):
     """Active blocks long enough for three bulge chains per sweep (chain c follows chain c-1 one window behind; 48 of the AED

@@ -28,6 +28,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "mfma.hpp"
 #include "prof.hpp"
@@ -35,9 +36,11 @@
 namespace trx {
 namespace {
 
-constexpr int QW = EigPlan::QW, QNS = EigPlan::QNS, QNMIN = EigPlan::QNMIN, QKC = EigPlan::QKC;
+constexpr int QW = EigPlan::QW, QNS = EigPlan::QNS, QKC = EigPlan::QKC;
 constexpr int SM = 64;             // largest matrix the in-LDS single-wave routines handle (one lane per column)
-constexpr int SLD = SM + 1;        // leading dimension of the small in-LDS matrices
+// The small in-LDS matrices have the RUNTIME leading dimension SLD = sm + 1, sm = the largest size the launch will meet (AED
+// window / small-block threshold): at the default 48 the prepare kernel needs 79 KB of LDS instead of 135 KB, which lets a
+// slab-update workgroup (74 KB) share its CU -- see the note on co-residency at hessenberg_qr.
 constexpr int QAED = EigPlan::QAED;   // aggressive-early-deflation window
 constexpr int QAED_MOVES = 12;        // undeflatable eigenvalues moved out of the way per AED
 
@@ -91,7 +94,7 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
 // rotation implicit chase this keeps every lane busy and needs no block barrier inside a QR iteration.
 // On return Hs is upper triangular; if Us != nullptr it holds U with H_in = U T U^H.  Returns false if not converged.
 template <class T>
-__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, long long* dbg = nullptr) {
+__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr) {
     const int lane = threadIdx.x;
     long long t_left = 0, t_right = 0, t_u = 0, t_pre = 0, tt = 0, n_it = 0, n_rot = 0;
     if (dbg) tt = clock64();
@@ -198,7 +201,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, long long
 // Swap the adjacent diagonal entries k, k+1 of the upper-triangular Ts (order m <= 64) by one rotation, accumulating into
 // Vs (LAPACK ztrexc for complex Schur forms).  One wave.
 template <class T>
-__device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k) {
+__device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k, const int SLD) {
     const int lane = threadIdx.x;
     const cx<T> a = Ts[k * SLD + k], bq = Ts[(k + 1) * SLD + k + 1], x = Ts[k * SLD + k + 1];
     const Rot<T> R = rotg_fast(x, bq - a);
@@ -248,7 +251,7 @@ __device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& 
 // Apply H = I - tau v v^H (v on rows/cols [o, o+len)) to the m x m Ts from both sides (Ts <- H^H Ts H, left side on
 // columns >= c0, right side on rows < nrows_t) and to Vs from the right (all m rows).  One wave, m <= 64.
 template <class T>
-__device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, int o, int len, int c0, const cx<T>* vw, cx<T> tau) {
+__device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, int o, int len, int c0, const cx<T>* vw, cx<T> tau, const int SLD) {
     const int lane = threadIdx.x;
     if (lane >= c0 && lane < m) {                                   // left: lane = column
         cx<T> w(T(0), T(0));
@@ -311,21 +314,23 @@ __device__ __forceinline__ int plan_chains(QrState& st, int ilo, int ihi, int av
 __device__ __forceinline__ int chain_shift_pos(const QrState& st, int ktot, int c, int s) { return ktot - QNS * c - st.k[c] + s; }
 
 template <class T>
-__global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ stall_,
+__global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        long long* dbg_all = nullptr) {
+                                                        int sm, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
-    cx<T>* Hs = reinterpret_cast<cx<T>*>(smem);                  // [SM][SLD]
-    cx<T>* Us = Hs + SM * SLD;                                   // [SM][SLD]
-    cx<T>* vwork = Us + SM * SLD;                                // [SM]
-    cx<T>* wk = vwork + SM;                                      // [SM]
-    Rot<T>* rots = reinterpret_cast<Rot<T>*>(wk + SM);           // [SM]
-    QrState& sst = *reinterpret_cast<QrState*>(rots + SM);
+    const int SLD = sm + 1;                                      // sm: largest small matrix of this launch (AED window = small-block threshold)
+    const int QNMIN = sm;                                        // active blocks up to this size are finished right here
+    cx<T>* Hs = reinterpret_cast<cx<T>*>(smem);                  // [sm][SLD]
+    cx<T>* Us = Hs + sm * SLD;                                   // [sm][SLD]
+    cx<T>* vwork = Us + sm * SLD;                                // [sm]
+    cx<T>* wk = vwork + sm;                                      // [sm]
+    Rot<T>* rots = reinterpret_cast<Rot<T>*>(wk + sm);           // [sm]
+    QrState& sst = *reinterpret_cast<QrState*>(rots + sm);
     const int b = blockIdx.x, lane = threadIdx.x;
-    cx<T>* H = Aall + (long)b * n * n;
+    cx<T>* H = Aall + (long)b * mstride;
     if (lane == 0) sst = stall_[b];
     __syncthreads();
     QrState st = sst;
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         bool unfinished = false;
         for (int c = 0; c < st.nch; ++c) unfinished = unfinished || (st.tau[c][par] <= st.tau_last[c]);
         if (unfinished) {
-            if (lane == 0) { atomicAdd(&summary[0], 1); atomicOr(&summary[2], 2); atomicMax(&summary[1], st.ihi - st.ilo + 1); }
+            if (lane == 0) { atomicAdd(&summary[0], 1); atomicOr(&summary[2], 2); atomicMax(&summary[1], st.ihi + 1); }
             return;
         }
     }
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
         }
         __syncthreads();
-        const bool ok = small_schur<T>(Hs, m, Us, rots);
+        const bool ok = small_schur<T>(Hs, m, Us, rots, SLD);
         __syncthreads();
         cx<T>* U = Uall + (long)b * QKC * QW * QW;            // chain slot 0 carries the unitary of a finished block / AED window
         for (int e = lane; e < m * m; e += 64) {
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
             atomicOr(&summary[2], 1);
+            atomicMax(&summary[1], st.ihi + 1);
         }
         return;
     }
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[6] += t1 - tk0; tk0 = t1; }       // scans + window load
-    const bool okw = small_schur<T>(Hs, nw, Us, rots, dbg);
+    const bool okw = small_schur<T>(Hs, nw, Us, rots, SLD, dbg);
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[7] += t1 - tk0; tk0 = t1; }       // Schur total
     int ns = nw;
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
                 --ns;                                                // deflatable
             } else {
                 if (moves >= aed_moves) break;
-                for (int kk = ns - 2; kk >= ilst; --kk) schur_swap<T>(Hs, Us, nw, kk);
+                for (int kk = ns - 2; kk >= ilst; --kk) schur_swap<T>(Hs, Us, nw, kk, SLD);
                 ++ilst; ++moves;
             }
         }
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             st.stall += 1; st.sweeps += 1; clear_windows(st);
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
-            atomicMax(&summary[1], m);
+            atomicMax(&summary[1], ihi + 1);
         }
         return;
     }
@@ -500,13 +506,13 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         __syncthreads();
         cx<T> tau; T beta;
         small_larfg<T>(wk, 1, ns, vw, tau, beta);
-        small_apply_reflector<T>(Hs, Us, nw, ns, 0, ns, 0, vw, tau);
+        small_apply_reflector<T>(Hs, Us, nw, ns, 0, ns, 0, vw, tau, SLD);
         for (int jc = 0; jc + 2 < ns; ++jc) {
             small_larfg<T>(Hs + (jc + 1) * SLD + jc, SLD, ns - jc - 1, vw, tau, beta);
             if (lane == 0) Hs[(jc + 1) * SLD + jc] = cx<T>(beta, T(0));
             if (lane >= 1 && lane < ns - jc - 1) Hs[(jc + 1 + lane) * SLD + jc] = cx<T>(T(0), T(0));
             __syncthreads();
-            small_apply_reflector<T>(Hs, Us, nw, ns, jc + 1, ns - jc - 1, jc + 1, vw, tau);
+            small_apply_reflector<T>(Hs, Us, nw, ns, jc + 1, ns - jc - 1, jc + 1, vw, tau, SLD);
         }
     }
     __syncthreads();
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
                 st.mode = QR_AED_CHASE;
                 st.ihi = ihi - nd;
                 st.sweeps = sw + 1;
-                atomicMax(&summary[1], m2);
+                atomicMax(&summary[1], st.ihi + 1);
             } else {
                 st.mode = QR_SMALL_PENDING;
             }
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
             atomicOr(&summary[2], 1);
+            atomicMax(&summary[1], st.ihi + 1);
             if (dbg) { const long long t1 = clock64(); dbg[10] += t1 - tk0; }                      // write-back
         }
     }
@@ -557,23 +564,32 @@ __device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, i
 // threads): a chain step is bound by the fp64 vector issue time of the 2 + 4 rotated element pairs per lane-quartet (cycle
 // counters, TRX_QR_DEBUG: 16 lanes per bulge spent 3600 cycles per step, ~2600 of them in the two rotation phases), so the
 // widest mapping the 64-wide window admits is the fastest one.
+// Two phases in ONE window-sized LDS buffer: (1) the chase on the H window, every rotation logged (c, s: 24 bytes); H written
+// back; (2) the same buffer becomes U = I and the log is replayed onto it (bulge s's wave rotates its two columns, one barrier
+// per chain step).  With H and U side by side the kernel needed 133 KB of LDS and could only start on a CU with NO slab-update
+// workgroup on it -- and since the slab updates of the other iteration groups refill free slots at once, window launches
+// starved until those kernels drained.  At 85 KB it shares a CU with one slab-update workgroup (74 KB).
 constexpr int LPB = 64;                    // lanes per bulge
 constexpr int WTHREADS = QNS * LPB;        // threads of the window kernel
 constexpr int WIT = QW / LPB;              // element pairs per lane and phase
-template <class T>
-__global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, int n, QrState* __restrict__ st_all,
+constexpr int WMAXS = 48;                  // chain steps per launch (rotation log: WMAXS x QNS entries)
+template <class T> struct RotCS { T c; cx<T> s; };
+// DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it (it must stay within
+// 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
+template <class T, bool DBG>
+__global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
-    long long* dbg = (dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;     // TRX_QR_DEBUG: cycle counters of matrix 0, chain 0
+    long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
-    cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]
-    cx<T>* Uw = Hw + QW * LD;                          // [QW][LD]
-    QrState& sst = *reinterpret_cast<QrState*>(Uw + QW * LD);
+    cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
+    RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
+    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
     __syncthreads();
-    const QrState st = sst;
+    const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
     // positions go to the [par] copy, which nobody writes in this step.
     if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
@@ -584,6 +600,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     int w0 = 0, w1 = 0, tau_end = 0;
     if (move) {
         chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
+        if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several launches
         if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
             // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
             // this step); this chain may only work strictly above it
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
         return;
     }
-    cx<T>* H = Aall + (long)b * n * n;
+    cx<T>* H = Aall + (long)b * mstride;
     const int ww = w1 - w0;
     {
         // window load: QW*QW/WTHREADS independent (clamped) global loads per thread in flight, then the LDS fill
@@ -615,10 +632,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int r = r4 + RSTEP * i;
-            if (r < ww && c < ww) {
-                Hw[r * LD + c] = hv[i];
-                Uw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
-            }
+            if (r < ww && c < ww) Hw[r * LD + c] = hv[i];
         }
     }
     const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
@@ -640,7 +654,8 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
             else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
             R = rotg_fast(f, g);
-        }
+        } else { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0)); }
+        if (j == 0) { rlog[(tau - tau0) * QNS + sb].c = R.c; rlog[(tau - tau0) * QNS + sb].s = R.s; }
         wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
         if (dbg) { const long long t1 = clock64(); dbg[16] += t1 - tk0; tk0 = t1; }
         if (active) {
@@ -665,21 +680,18 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { const long long t1 = clock64(); dbg[18] += t1 - tk0; tk0 = t1; }
         if (active) {
             const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
-            cx<T> xh[WIT], yh[WIT], xu[WIT], yu[WIT];
+            cx<T> xh[WIT], yh[WIT];
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int row = j + LPB * it;
-                const int rh = row <= hi ? row : hi, ru = row < ww ? row : ww - 1;
+                const int rh = row <= hi ? row : hi;
                 xh[it] = Hw[rh * LD + q]; yh[it] = Hw[rh * LD + q + 1];
-                xu[it] = Uw[ru * LD + q]; yu[it] = Uw[ru * LD + q + 1];
             }
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int row = j + LPB * it;
                 rot_cols(R, xh[it], yh[it]);
-                rot_cols(R, xu[it], yu[it]);
                 if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
-                if (row < ww) { Uw[row * LD + q] = xu[it]; Uw[row * LD + q + 1] = yu[it]; }
             }
         }
         if (dbg) { const long long t1 = clock64(); dbg[19] += t1 - tk0; tk0 = t1; }
@@ -688,17 +700,53 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     }
     if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
     cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
     {
-        constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
+        // phase 1 done: the window goes back to H, the buffer becomes U = I
+        const int c = t & (QW - 1), r4 = t / QW;
+        cx<T> hv[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = r4 + RSTEP * i;
+            if (r < ww && c < ww) H[(long)(w0 + r) * n + w0 + c] = hv[i];
+            Hw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+        }
+    }
+    __syncthreads();
+    // phase 2: replay the logged rotations onto U (right multiplications; within a chain step the bulges own disjoint column pairs)
+    for (int tau = tau0; tau <= tau_end; ++tau) {
+        const int p = ilo + tau - 2 * sb;
+        const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
+        if (active) {
+            const int q = p - w0;
+            Rot<T> R;
+            R.c = rlog[(tau - tau0) * QNS + sb].c; R.s = rlog[(tau - tau0) * QNS + sb].s;
+            cx<T> xu[WIT], yu[WIT];
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int row = j + LPB * it;
+                const int ru = row < ww ? row : ww - 1;
+                xu[it] = Hw[ru * LD + q]; yu[it] = Hw[ru * LD + q + 1];
+            }
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int row = j + LPB * it;
+                rot_cols(R, xu[it], yu[it]);
+                if (row < ww) { Hw[row * LD + q] = xu[it]; Hw[row * LD + q + 1] = yu[it]; }
+            }
+        }
+        __syncthreads();
+    }
+    {
         const int c = t & (QW - 1), r4 = t / QW;
         if (c < ww) {
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int r = r4 + RSTEP * i;
-                if (r < ww) {
-                    H[(long)(w0 + r) * n + w0 + c] = Hw[r * LD + c];
-                    U[r * QW + c] = Uw[r * LD + c];
-                }
+                if (r < ww) U[r * QW + c] = Hw[r * LD + c];
             }
         }
     }
@@ -714,11 +762,16 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
 // (split re/im planes) and serves as the A operand of the left update (U^H: the conjugation is folded into the signs of the
 // four real MFMAs) and as the B operand of the right update; the streamed operand goes global memory -> registers directly
 // in MFMA fragment layout (no LDS staging, no barrier after the prologue), and the next strip of the wave is prefetched into
-// registers while the current one is multiplied.  The k index of an MFMA step is permuted (k = 16c + 4*(lane>>4) + j) so that
+// registers while the current one is multiplied.  The k index of an MFMA step is permuted (k = 16c + 4*(lane>>4) + j, kstep()) so that
 // a lane of the right update reads 4 consecutive elements of its row; both operands use the same permutation.
 // Algorithmic intensity: 8*16*64*64 flops per 2*16 KiB moved = 16 flop/B, i.e. the update sits at the MFMA/HBM balance point
 // (78.6 TF / 16 = 4.9 TB/s): every byte is touched exactly once per window step.
 constexpr int MLD = 72;           // LDS plane row stride: element U[k][c] at [k*MLD + c]
+// k index a lane of k-group lk (= lane >> 4) supplies at MFMA step (h, cc, j): k = kstep(h, cc, j) + KLS * lk.  Permuted order
+// (16 c + 4 lk + j): the four loads (j) of a lane of the right update are 64 contiguous bytes.  The natural order 4 step + lk
+// (the four k-groups of ONE instruction contiguous instead) was measured too: 28.0 vs 28.4 solves/s, so the permutation stays.
+constexpr int KLS = 4;
+__device__ __forceinline__ constexpr int kstep(int h, int cc, int j) { return 16 * (2 * h + cc) + j; }
 
 template <class T>
 struct SlabStrip {       // wave-uniform description of one strip
@@ -739,16 +792,31 @@ __device__ __forceinline__ SlabStrip<T> slab_locate(int g, int nL, int nR, cx<T>
     return d;
 }
 
-// registers x[4cc + j] <- streamed operand element k = 16(2h + cc) + 4lk + j (half h of the strip's K range) of this lane's
+// registers x[4cc + j] <- streamed operand element k = kstep(h, cc, j) + lk (half h of the strip's K range) of this lane's
 // column (left) / row (right).  Out-of-range coordinates are CLAMPED to a valid element of the same matrix and the value is
 // used as is: for k >= ww it meets a zero row of the padded U in LDS, and a lane whose row / column lies outside the region
 // only feeds output elements that are never stored.  (No select after the load: the loaded registers have no consumer until
 // the MFMAs of the next strip, so the loads stay in flight behind the current strip's arithmetic.)
-template <class T>
+// FULL (the window has all QW rows / columns: no clamp on k): the address is split into ONE lane-dependent 32-bit offset per strip
+// and a wave-uniform part per load that goes into the scalar base, so that 16 loads cost one address register instead of 16.
+template <class T, bool FULL = false>
 __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int n, int w0, int ww, int lane, cx<T> (&x)[8]) {
     const int lr = lane & 15, lk = lane >> 4;
     const int a = d.a0 + lr;
     const int ac = a < d.lim ? a : d.lim - 1;
+    if constexpr (FULL) {
+        const unsigned ksu = (d.side == 0 ? (unsigned)n : 1u) * (unsigned)sizeof(cx<T>);                 // wave-uniform
+        const unsigned lane_off = (d.side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>) + (unsigned)(KLS * lk) * ksu;
+        const char* base = reinterpret_cast<const char*>(d.X);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* pb = base + (size_t)kstep(h, cc, j) * ksu;                                        // scalar
+                x[4 * cc + j] = *reinterpret_cast<const cx<T>*>(pb + lane_off);
+            }
+        return;
+    }
     // 32-bit BYTE offsets from the wave-uniform matrix base (scalar base + 32-bit vector offset addressing; one address
     // register per access instead of two): requires n*n*sizeof(cx<T>) < 4 GiB, i.e. n < 16384 for complex128 (checked on the host)
     const unsigned p0 = (d.side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>);
@@ -758,7 +826,7 @@ __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = 16 * (2 * h + cc) + 4 * lk + j;
+            const int k = kstep(h, cc, j) + KLS * lk;
             x[4 * cc + j] = *reinterpret_cast<const cx<T>*>(base + (p0 + (unsigned)(k < ww ? k : ww - 1) * ks));
         }
 }
@@ -771,7 +839,7 @@ __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, con
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int off = (16 * (2 * h + cc) + 4 * lk + j) * MLD + lr;
+            const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
             T ur[4], ui[4];
 #pragma unroll
@@ -815,7 +883,7 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int off = (16 * (2 * h + cc) + 4 * lk + j) * MLD + lr + 32 * pp;
+            const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 32 * pp;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
             const T xs = xr + xi;
             T ur[2], ui[2], us[2];
@@ -839,14 +907,50 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
 #pragma unroll
                 for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
             }
+            // bound the hoisting of the U fragment reads to the next two k-steps: unbounded, hipcc keeps the fragments of a whole K half
+            // live (96 registers), which the register double buffer of the streamed operand has no room for
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
-template <class T>
+// FULL: `w0` is the origin of a full QW-wide window frame and `ww` packs the range of frame indices that belong to the real window
+// (klo | khi << 8): only those rows (left update) / columns (right update) are stored, the identity-padded rest is left untouched.
+template <class T, bool FULL = false>
 __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, int w0, int ww, int lane, int pp, const typename Mfma<T>::acc_t (&accR)[2],
                                                 const typename Mfma<T>::acc_t (&accI)[2]) {
     const int lr = lane & 15;
     char* base = reinterpret_cast<char*>(d.X);       // scalar base + 32-bit byte offsets, as in slab_load_half
+    if constexpr (FULL) {
+        // one lane-dependent offset; the (r, q) part of every store is wave-uniform and moves into the scalar base
+        const int cr0 = Mfma<T>::crow(lane, 0), rs = Mfma<T>::crow(0, 1) - Mfma<T>::crow(0, 0);
+        const unsigned esz = (unsigned)sizeof(cx<T>);
+        const int klo = ww & 255, khi = ww >> 8;
+        if (d.side == 1) {
+            const unsigned lane_off = ((unsigned)(d.a0 + cr0) * n + w0 + lr) * esz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool okr = d.a0 + cr0 + r * rs < d.lim;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int k = 16 * (2 * pp + q2) + lr;
+                    char* pb = base + ((size_t)(r * rs) * n + 16 * (2 * pp + q2)) * esz;
+                    if (okr && k >= klo && k < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(accR[q2][r], accI[q2][r]);
+                }
+            }
+        } else {
+            const unsigned lane_off = ((unsigned)(w0 + cr0) * n + d.a0 + lr) * esz;
+            const bool okc = d.a0 + lr < d.lim;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int i = 16 * (2 * pp + q2) + cr0 + r * rs;
+                    char* pb = base + (size_t)(16 * (2 * pp + q2) + r * rs) * n * esz;
+                    if (okc && i >= klo && i < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(accR[q2][r], accI[q2][r]);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cr = Mfma<T>::crow(lane, r);
@@ -865,12 +969,23 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
     }
 }
 
+template <class T, int SIDE, bool FULL = false>
+__device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
+                                             const cx<T> (&xa)[8], const cx<T> (&xb)[8]);
+
 template <class T, int SIDE>
 __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane) {
     cx<T> xa[8], xb[8];
     slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
     slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
+    slab_compute<T, SIDE>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+}
+
+// multiply + store of one strip whose streamed operand is already in (or on its way to) registers
+template <class T, int SIDE, bool FULL>
+__device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
+                                             const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
     if constexpr (sizeof(T) == 8) {
         // fp64: 3M product, two of the four output tiles at a time (the streamed operand stays in registers for both passes, the
         // U fragments of the second pass are other columns of the same LDS planes): 48 accumulator registers instead of 64, a
@@ -892,7 +1007,7 @@ __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __
                     p1[q][r] = SIDE == 1 ? a - b : a + b;               // real part
                     p2[q][r] = SIDE == 1 ? c - a - b : c - a + b;       // imaginary part
                 }
-            slab_store_pair<T>(d, n, w0, ww, lane, pp, p1, p2);
+            slab_store_pair<T, FULL>(d, n, w0, ww, lane, pp, p1, p2);
         }
         return;
     }
@@ -942,7 +1057,7 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 // exactly would otherwise run a second, nearly empty round of workgroups on the CUs that are left; with dynamic claiming a
 // workgroup that starts late finds the counter exhausted and leaves, and the launch ends when the work does.
 template <class T, int SPW, int PART>
-__global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, int n,
+__global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                            QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
                                                            unsigned* __restrict__ work, int nslab, int dynamic) {
     TRX_DYN_SMEM(smem);
@@ -970,8 +1085,8 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
     }
     __syncthreads();
-    cx<T>* H = Aall + (long)b * n * n;
-    cx<T>* Z = Zall + (long)b * n * n;
+    cx<T>* H = Aall + (long)b * mstride;
+    cx<T>* Z = Zall + (long)b * mstride;
     if (PART == 2 && dynamic) {
         // dynamic claiming; the next claim is issued before the current strip is processed, so that the round trip of the atomic
         // (1-2 us) hides behind a strip's worth of loads and MFMAs (a wave over-claims once at the end: harmless)
@@ -980,8 +1095,7 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
             if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
             return __builtin_amdgcn_readfirstlane(g);
         };
-        int g = claim();
-        while (g < S) {
+        for (int g = claim(); g < S;) {
             const int gn = claim();
             const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
             if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
@@ -999,17 +1113,156 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     }
 }
 
+// One 16x16 output tile (tile q of the strip) with the 3M product over the full K = QW, then its store: the unit of work of the
+// software-pipelined kernel below.  A single tile keeps only 24 accumulator registers live next to the two 64-register operand
+// buffers; the streamed operand is reused from registers by all four tiles, the U fragments come from LDS per tile.
+template <class T, int SIDE>
+__device__ __forceinline__ void slab_tile_3m(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int ws0, int krange, int lane, int q,
+                                             const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
+    const int lr = lane & 15, lk = lane >> 4;
+    typename Mfma<T>::acc_t p1, p2, p3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p1[r] = T(0); p2[r] = T(0); p3[r] = T(0); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 16 * q;
+                const cx<T> xv = h == 0 ? xa[4 * cc + j] : xb[4 * cc + j];
+                const T xs = xv.x + xv.y;
+                const T ur = Ur[off], ui = Ui[off];
+                if (SIDE == 1) {          // C = X U
+                    p1 = Mfma<T>::mma(xv.x, ur, p1);
+                    p2 = Mfma<T>::mma(xv.y, ui, p2);
+                    p3 = Mfma<T>::mma(xs, ur + ui, p3);
+                } else {                  // C = U^H X
+                    p1 = Mfma<T>::mma(ur, xv.x, p1);
+                    p2 = Mfma<T>::mma(ui, xv.y, p2);
+                    p3 = Mfma<T>::mma(ur - ui, xs, p3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // bounds the hoisting of the U fragment reads (4 k-steps at a time)
+        }
+    // Cr, Ci from the three products, then the store of the tile (frame indices outside [klo, khi) are identity padding: skipped)
+    const int cr0 = Mfma<T>::crow(lane, 0), rs = Mfma<T>::crow(0, 1) - Mfma<T>::crow(0, 0);
+    const unsigned esz = (unsigned)sizeof(cx<T>);
+    const int klo = krange & 255, khi = krange >> 8;
+    char* base = reinterpret_cast<char*>(d.X);
+    if (SIDE == 1) {
+        const unsigned lane_off = ((unsigned)(d.a0 + cr0) * n + ws0 + lr) * esz;
+        const int k = 16 * q + lr;
+        const bool okk = k >= klo && k < khi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T a = p1[r], bb = p2[r], c = p3[r];
+            char* pb = base + ((size_t)(r * rs) * n + 16 * q) * esz;
+            if (okk && d.a0 + cr0 + r * rs < d.lim) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(a - bb, c - a - bb);
+        }
+    } else {
+        const unsigned lane_off = ((unsigned)(ws0 + cr0) * n + d.a0 + lr) * esz;
+        const bool okc = d.a0 + lr < d.lim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T a = p1[r], bb = p2[r], c = p3[r];
+            const int i = 16 * q + cr0 + r * rs;
+            char* pb = base + (size_t)(16 * q + r * rs) * n * esz;
+            if (okc && i >= klo && i < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(a + bb, c - a + bb);
+        }
+    }
+}
+template <class T, int SIDE>
+__device__ __forceinline__ void slab_strip_tiles(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int ws0, int krange, int lane,
+                                                 const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) slab_tile_3m<T, SIDE>(Ur, Ui, d, n, ws0, krange, lane, q, xa, xb);
+}
+
+// Software-pipelined variant of the single-launch update (fp64, one chain, n >= 2 QW): the loads of the NEXT strip are issued
+// before the current one is multiplied (register double buffer: 2 x 64 operand registers + 48 accumulators of the 3M tile pairs),
+// so the matrix cores do not wait out an HBM round trip per strip -- alone on the chip the one-strip-at-a-time kernel ran at 39 %
+// of the time its MFMAs need (rocprofv3 timeline: 100 us for a launch whose matrix-core work is 39 us).  To keep ONE code path in
+// the register budget every window is treated as a full QW-wide frame: its origin is moved up when it would stick out of the
+// matrix (ws0 = min(w0, n - QW)) and U is embedded in an identity of size QW; loads need no clamp on the window index, and the
+// stores skip the identity rows / columns (slab_store_pair<FULL>), so nothing outside the real window is rewritten.
 template <class T>
-__global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __restrict__ info, int batch) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < batch) info[b] = st[b].fail;
+__global__ __launch_bounds__(256, 2) void apply_window_pipe_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+                                                                QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall, unsigned* __restrict__ work) {
+    TRX_DYN_SMEM(smem);
+    T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
+    T* Ui = Ur + QW * MLD;
+    const int b = blockIdx.y;
+    const int w0 = st_all[b].w0[0], w1 = st_all[b].w1[0];
+    const int ww = w1 - w0;
+    if (ww <= 0) return;
+    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
+    const int S = nL + nR + nZ;
+    const int t = threadIdx.x, lane = t & 63;
+    if (blockIdx.x == 0 && t == 0) atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
+    const int ws0 = w0 < n - QW ? w0 : n - QW;          // origin of the QW-wide frame
+    const int sh = w0 - ws0;                            // the real window sits at frame indices [sh, sh + ww)
+    const int krange = sh | ((sh + ww) << 8);
+    const cx<T>* U = Uall + (long)b * QKC * QW * QW;
+    for (int e = t; e < QW * QW; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        const int kk = k - sh, cc = c - sh;
+        cx<T> u(k == c ? T(1) : T(0), T(0));
+        if (kk >= 0 && kk < ww && cc >= 0 && cc < ww) u = U[kk * QW + cc];
+        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+    }
+    __syncthreads();
+    cx<T>* H = Aall + (long)b * mstride;
+    cx<T>* Z = Zall + (long)b * mstride;
+    // STATIC strip assignment here (wave w of workgroup x takes strips x*4*spw + w + 4 i): a dynamic claim is an atomic with return,
+    // and hipcc waits for it with vmcnt(0) right where it is issued (its wave-level atomic optimiser reads the result back at once),
+    // which also waits out every prefetch load in flight -- seen in the ISA, and measured: no gain from the pipeline with it.  The
+    // prefetch is unconditional (a wave past its last strip re-reads that strip and discards it), so there is no branch between
+    // the issue of the loads and the MFMAs that hide them; the waits in front of the MFMAs are vmcnt(16..25), i.e. they leave the
+    // 16 loads of the next strip in flight.
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int spw = (S + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x);          // strips per wave
+    const int gbase = blockIdx.x * 4 * spw + wave;
+    const int gend = (blockIdx.x + 1) * 4 * spw < S ? (blockIdx.x + 1) * 4 * spw : S;     // this workgroup's strips: [blockIdx.x*4*spw, gend)
+    if (gbase >= gend) return;
+    SlabStrip<T> d0 = slab_locate<T, 2>(gbase, nL, nR, H, Z, n, w0, w1), d1 = d0;
+    cx<T> xa0[8], xb0[8], xa1[8], xb1[8];
+    slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
+    slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
+    for (int g = gbase;; g += 8) {
+        const int gb = g + 4, gc = g + 8;
+        d1 = slab_locate<T, 2>(gb < gend ? gb : g, nL, nR, H, Z, n, w0, w1);
+        slab_load_half<T, true>(d1, 0, n, ws0, QW, lane, xa1);
+        slab_load_half<T, true>(d1, 1, n, ws0, QW, lane, xb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d0.side == 0) slab_strip_tiles<T, 0>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
+        else slab_strip_tiles<T, 1>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
+        if (gb >= gend) break;
+        d0 = slab_locate<T, 2>(gc < gend ? gc : gb, nL, nR, H, Z, n, w0, w1);
+        slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
+        slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d1.side == 0) slab_strip_tiles<T, 0>(Ur, Ui, d1, n, ws0, krange, lane, xa1, xb1);
+        else slab_strip_tiles<T, 1>(Ur, Ui, d1, n, ws0, krange, lane, xa1, xb1);
+        if (gc >= gend) break;
+    }
+}
+
+template <class T>
+__global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __restrict__ info, int batch, int ngroups) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;       // matrix b belongs to group b % ngroups, at position b / ngroups of it
+    if (b >= batch) return;
+    const int g = b % ngroups, local = b / ngroups;
+    int b0 = 0;
+    for (int h = 0; h < g; ++h) b0 += (batch - h + ngroups - 1) / ngroups;       // state slots are group-contiguous
+    info[b] = st[b0 + local].fail;
 }
 
 }  // namespace
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1028,6 +1281,9 @@ static QrKnobs& qr_knobs() {
         q.nibble = geti("TRX_QR_NIBBLE", 0, 100, 100);
         q.moves = geti("TRX_QR_MOVES", 0, QAED, QAED_MOVES);
         q.chains = geti("TRX_QR_CHAINS", 1, QKC, 0);
+        q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
+        q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
+        q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1036,7 +1292,14 @@ static QrKnobs& qr_knobs() {
 
 // Non-blocking streams and timing-less events for the iteration groups, created on first use and kept for the life of the
 // process (per device); a call checks out what it needs and hands it back, so concurrent callers never share one.
-struct QrLane { hipStream_t s = nullptr; hipEvent_t ev = nullptr; int dev = -1; bool has_stream = false; };
+struct QrLane {
+    hipStream_t s = nullptr;
+    hipEvent_t ev = nullptr;           // fork / join / start stagger
+    hipEvent_t evs[2] = {nullptr, nullptr};   // "summary of iteration k has landed in hsum[k % 2]"
+    int* hsum = nullptr;               // pinned host memory, 2 x 4 ints
+    int dev = -1;
+    bool has_stream = false;
+};
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
@@ -1050,6 +1313,8 @@ static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
     out.has_stream = want_stream;
     if (want_stream && hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&out.ev, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&out.evs[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&out.evs[1], hipEventDisableTiming) != hipSuccess) return false;
+    if (hipHostMalloc((void**)&out.hsum, sizeof(int) * 8, hipHostMallocDefault) != hipSuccess) return false;
     return true;
 }
 static void lane_return(const QrLane& l) {
@@ -1069,6 +1334,9 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_nibble") { slot = &k.nibble; hi = 100; }
     else if (s == "qr_moves") { slot = &k.moves; hi = QAED; }
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
+    else if (s == "slab_dyn") { slot = &k.dyn; hi = 2; }
+    else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
+    else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1080,19 +1348,18 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     constexpr int LD = QW + 1;
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
-    const size_t sm2 = sizeof(cx<T>) * 2 * QW * LD;
-    const size_t smw = sm2 + sizeof(QrState);
+    const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
     const size_t sma = sizeof(T) * 2 * QW * MLD;
-    const size_t smp = sizeof(cx<T>) * (2 * SM * SLD + 2 * SM) + sizeof(Rot<T>) * SM + sizeof(QrState);
+    auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
     static std::once_flag attr_once[2];
     int attr_rc = 0;
     std::call_once(attr_once[sizeof(T) == 8], [&] {
-        attr_rc = set_max_dyn_smem((const void*)qr_window_kernel<T>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
+        attr_rc = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) ||
-                  set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp);
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
+                  set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp_of(SM));
     });
     if (attr_rc) return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
@@ -1109,6 +1376,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // update they need costs 10 % on its own: 26.5 (1 chain, one launch) vs 22.1 / 21.9 solves/s at batch 128, 12.1 vs 11.3 at
     // batch 16.  One chain is the default; the knob stays for other spectra.
     const int kc = K.chains ? K.chains : 1;
+    // software-pipelined slab kernel: knob slab_pipe = 2 switches it on.  Measured on MI355X at batch 128 it is NOT faster than the
+    // one-strip-at-a-time kernel with dynamically claimed strips (27.4-28.0 vs 28.4 solves/s): a launch of the latter already
+    // overlaps the loads of one wave with the MFMAs of its SIMD neighbour, and the static strips the pipeline needs bring back
+    // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
+    const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1120,10 +1392,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         QrLane lane;           // stream (null: the caller's) + event
         hipStream_t s;
         int b0, nb;
-        int* summary;          // device, 8 ints: [0] active matrices, [1] largest chase length, [2] flags, [3] slab work (cumulative)
+        int* summary;          // device, 8 ints: two slots {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] slab work (cumulative)
         bool done;
         unsigned work;
         int par;               // parity of the next window step (double-buffered chase positions)
+        int g;                 // group index = index of its first matrix
+        int issued, read;      // outer iterations queued / summaries read
     };
     // 4 groups = the number of hardware queues a HIP process gets by default; beyond that streams share queues and serialise
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
@@ -1137,12 +1411,16 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     }
     for (int g = 0; g < ngroups; ++g) {
         Group& G = grp[g];
-        G.b0 = (int)((long)batch * g / ngroups);
-        G.nb = (int)((long)batch * (g + 1) / ngroups) - G.b0;
+        // Group g takes the matrices g, g + ngroups, g + 2 ngroups, ... (NOT a contiguous block): the cost of a matrix varies
+        // smoothly along a sweep (wavelength, geometry), so contiguous blocks finish at very different times and the last
+        // group runs alone; interleaved, every group sees the same mix.  State, U and shift slots stay group-contiguous (b0).
+        G.nb = (batch - g + ngroups - 1) / ngroups;
+        G.b0 = g == 0 ? 0 : grp[g - 1].b0 + grp[g - 1].nb;
         G.summary = B.summary + 8 * g;
         G.done = false;
         G.work = 0;
         G.par = 0;
+        G.g = g;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
         ++nlanes;
         G.s = g == 0 ? s : G.lane.s;
@@ -1150,87 +1428,132 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     }
     // AED window: 64 deflates most per call (fewest sweeps, least slab work) but costs 3 ms of single-wave latency; at small
     // batches, where nothing is throughput bound, a smaller window shortens the chain
-    const int aed_w = K.aed ? K.aed : (batch >= 64 ? QAED : 48);
+    const long mstride = (long)ngroups * n * n;              // distance between consecutive matrices of one group
+    const int aed_w = K.aed ? K.aed : (batch >= 64 ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48
+    const size_t smp = smp_of(aed_w);
     // LAPACK skips the sweep when AED deflated more than 14 % of the window ("nibble") because there the sweep is the expensive
     // part.  Here the AED is, so every AED that leaves an active block is followed by a sweep in the same iteration.
     const int nibble = K.nibble, aed_moves = K.moves;
     const bool qr_debug = K.debug;                                        // cycle breakdown of the prepare / window kernels (matrix 0) to stderr
     long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 64);    // 24 counters behind the group summaries
-    auto issue_prepare = [&](Group& G) -> bool {
-        if (hipMemsetAsync(G.summary, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;      // [3] keeps accumulating
-        ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
-        TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.b0 * n * n, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                   B.shifts + (long)G.b0 * QKC * QNS, G.summary, max_sweeps, aed_w, nibble, aed_moves, G.par, kc,
-                   (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
-        return true;
+    // One outer iteration of a group = the window steps of its sweep followed by the next prepare (deflation scan, AED, shifts)
+    // and the copy of that prepare's 16-byte summary into pinned host memory.  The host runs ONE ITERATION AHEAD of what it has
+    // read: iteration k+1 is queued with a step count from summary k-1 -- summary[1] is an upper bound (ihi + 1) for every block
+    // the matrices of the group can still work on, and it only shrinks; a step a chain does not need is a kernel that exits at
+    // once.  So a stream never drains while the host is busy with another group (with one queued iteration per group and a
+    // blocking read the groups ran mostly ONE AT A TIME: rocprofv3 timeline, profiles/).
+    auto issue_prepare = [&](Group& G, int slot) -> bool {
+        int* sum = G.summary + 4 * slot;
+        if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
+        { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
+          TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
+                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
+                     (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
+        if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
+        return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
     };
-    if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
-    // first prepares are chained (group g starts when group g-1 has finished its own) so that the groups start out of phase
-    for (int g = 0; g < ngroups && !rc; ++g) {
-        if (g > 0 && hipStreamWaitEvent(grp[g].s, grp[g - 1].lane.ev, 0) != hipSuccess) rc = TRX_ERR_LAUNCH;
-        if (!rc && !issue_prepare(grp[g])) rc = TRX_ERR_LAUNCH;
-        if (!rc && ngroups > 1 && hipEventRecord(grp[g].lane.ev, grp[g].s) != hipSuccess) rc = TRX_ERR_LAUNCH;
-    }
-    int live = rc ? 0 : ngroups;
-    for (long visit = 0; live > 0 && visit < (long)ngroups * (64L * n + 1000); ++visit) {
-        Group& G = grp[visit % ngroups];
-        if (G.done) continue;
-        int summary[4];
-        if (hipMemcpyAsync(summary, G.summary, sizeof(int) * 4, hipMemcpyDeviceToHost, G.s) != hipSuccess || hipStreamSynchronize(G.s) != hipSuccess) {
-            fprintf(stderr, "libtrx: HIP call failed at %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(hipGetLastError()));
-            rc = TRX_ERR_LAUNCH;
-            break;
-        }
-        G.work = (unsigned)summary[3];
-        if (summary[0] == 0) { G.done = true; --live; continue; }
-        cx<T>* Ag = B.A + (long)G.b0 * n * n;
-        cx<T>* Zg = B.Z + (long)G.b0 * n * n;
+    auto issue_sweep = [&](Group& G, int bound) {
+        cx<T>* Ag = B.A + (long)G.g * n * n;
+        cx<T>* Zg = B.Z + (long)G.g * n * n;
         cx<T>* Ug = B.U + (long)G.b0 * QKC * QW * QW;
         const cx<T>* shg = B.shifts + (long)G.b0 * QKC * QNS;
         QrState* stg = B.st + G.b0;
-        // window steps of this sweep: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary),
-        // every further chain enters about 3 steps behind the one ahead (blocking rule in qr_window_kernel); a chain that is
-        // still under way after that (flag 2 of the summary) just gets more steps
-        int nwin = 1;
-        if (summary[1] > 0) nwin = cdiv_i(summary[1] + 2 * QNS, adv) + 2 + 4 * (kc - 1);
+        // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary, + first / last window
+        // in up to two launches each), every further chain enters about 3 steps behind the one ahead
+        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 4 + 4 * (kc - 1) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              TRX_LAUNCH((qr_window_kernel<T>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, n, stg, Ug, shg, G.par, (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
               // (about two workgroups per CU over the group), whatever the group size
               // (groups of fewer than 16 matrices are latency bound and nothing competes for their CUs: static strips, measured faster)
-              const int dyn = G.nb >= 16;
+              const int dyn = K.dyn ? K.dyn - 1 : (G.nb >= 16);
               int wgm = cdiv_i(2 * nstrip + 2, 4 * spw);
               if (dyn) {
-                  wgm = 512 / G.nb;
-                  wgm = wgm < 8 ? 8 : (wgm > 32 ? 32 : wgm);      // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
+                  wgm = (K.wgs ? K.wgs : 512) / G.nb;
+                  wgm = wgm < 1 ? 1 : (wgm > 32 ? 32 : wgm);      // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
                   if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
               }
               const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(wgm, G.nb);
-              if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+              if (kc == 1 && dyn && pipe) {
+                  if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk);
+              } else if (kc == 1) {
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
               } }
         }
-        if (!issue_prepare(G)) { rc = TRX_ERR_LAUNCH; break; }
+    };
+    if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
+    // iteration 0 = the first prepare (chained: group g starts when group g-1 has finished its own, so that the groups start out of
+    // phase); iteration 1 = the first sweep, queued at once with the full matrix as its bound
+    for (int g = 0; g < ngroups && !rc; ++g) {
+        Group& G = grp[g];
+        if (g > 0 && hipStreamWaitEvent(G.s, grp[g - 1].lane.ev, 0) != hipSuccess) rc = TRX_ERR_LAUNCH;
+        if (!rc && !issue_prepare(G, 0)) rc = TRX_ERR_LAUNCH;
+        if (!rc && ngroups > 1 && hipEventRecord(G.lane.ev, G.s) != hipSuccess) rc = TRX_ERR_LAUNCH;
+        G.issued = 1;
+        G.read = 0;
     }
+    for (int g = 0; g < ngroups && !rc; ++g) {
+        Group& G = grp[g];
+        issue_sweep(G, n);
+        if (!issue_prepare(G, 1)) rc = TRX_ERR_LAUNCH;
+        G.issued = 2;
+    }
+    // The host serves whichever group's summary has landed (event query), never a fixed round-robin with a blocking wait: a group
+    // the GPU happened to favour would otherwise drain its queue and idle until the host had waited out the slower ones.
+    int live = rc ? 0 : ngroups;
+    long served = 0;
+    int idle_passes = 0;
+    while (live > 0 && served < (long)ngroups * (64L * n + 1000)) {
+        bool any = false;
+        for (int g = 0; g < ngroups && !rc; ++g) {
+            Group& G = grp[g];
+            if (G.done) continue;
+            const int slot = G.read & 1;
+            const hipError_t q = hipEventQuery(G.lane.evs[slot]);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+            any = true;
+            ++served;
+            const int active = G.lane.hsum[4 * slot], bound = G.lane.hsum[4 * slot + 1];
+            ++G.read;
+            if (active == 0) { G.done = true; --live; continue; }       // (the iteration already queued behind it finds nothing to do)
+            // summary G.read-1 is in: queue iteration G.issued (slot parity = G.issued & 1 = slot, free again now)
+            issue_sweep(G, bound);
+            if (!issue_prepare(G, G.issued & 1)) { rc = TRX_ERR_LAUNCH; break; }
+            ++G.issued;
+        }
+        if (rc) break;
+        if (any) { idle_passes = 0; continue; }
+        // nothing ready: block on the group that is furthest behind (its summary is the next to arrive, by and large)
+        if (++idle_passes < 64) { std::this_thread::yield(); continue; }
+        idle_passes = 0;
+        int gmin = -1;
+        for (int g = 0; g < ngroups; ++g)
+            if (!grp[g].done && (gmin < 0 || grp[g].read < grp[gmin].read)) gmin = g;
+        if (gmin >= 0 && hipEventSynchronize(grp[gmin].lane.evs[grp[gmin].read & 1]) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+    }
+    (void)hipGetLastError();          // hipEventQuery leaves hipErrorNotReady as the thread's last error
     double work = 0;
     for (int g = 0; g < nlanes; ++g) {
         Group& G = grp[g];
-        work += G.work;
+        if (!rc && prof_enabled() && hipMemcpyAsync(&G.work, G.summary + 3, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess)
+            work += G.work;
         if (g > 0) {
             // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
             if (hipEventRecord(G.lane.ev, G.s) != hipSuccess || hipStreamWaitEvent(s, G.lane.ev, 0) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
@@ -1248,7 +1571,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                     h[11], h[6], h[7], h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[12], h[13], h[15], h[14], h[16], h[17], h[18], h[19], h[20]);
     }
     if (prof_enabled()) prof_add_work(PROF_QR_APPLY_RIGHT, 8.0 * 4096.0 * work, 0.0);
-    TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch);
+    TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch, ngroups);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
