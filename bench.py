@@ -332,7 +332,7 @@ def main():
         barrier()
         if profile:
             engine.lib.prof_reset()
-            engine.lib.prof_enable(1)
+            engine.lib.prof_enable(0 if os.environ.get("TRX_BENCH_NOPROF") == "1" else 1)
             if not EMU:
                 mstat["timed0"] = torch.cuda.memory_stats(device)
         t0 = time.perf_counter()

@@ -205,6 +205,10 @@ if __name__ == "__main__":
         excerpt(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else 0.55)
     elif len(sys.argv) > 2 and sys.argv[2] == "--concurrency":
         concurrency(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "--gaps-frac":
+        con = sqlite3.connect(sys.argv[1])
+        t0, t1 = con.cursor().execute("select min(start), max(end) from kernels").fetchone()
+        gaps(sys.argv[1], from_ms=float(sys.argv[3]) * (t1 - t0) / 1e6, min_us=20.0)
     elif len(sys.argv) > 2 and sys.argv[2] == "--gaps":
         gaps(sys.argv[1], from_ms=float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
     elif len(sys.argv) > 2 and sys.argv[2] == "--phases":

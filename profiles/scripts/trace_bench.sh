@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/tr_$TAG -o t 
 DB=$(find /tmp/tr_$TAG -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py $DB 45 > $R/gpurun_out/${TAG}_kernel_stats.txt
 python $R/profiles/kernel_stats.py $DB --phases > $R/gpurun_out/${TAG}_phases.txt
-python $R/profiles/kernel_stats.py $DB --gaps 0 > $R/gpurun_out/${TAG}_gaps.txt
+python $R/profiles/kernel_stats.py $DB --gaps-frac 0.55 > $R/gpurun_out/${TAG}_gaps.txt
 python $R/profiles/kernel_stats.py $DB --concurrency > $R/gpurun_out/${TAG}_concurrency.txt 2>&1
 python $R/profiles/kernel_stats.py $DB --excerpt 0.55 > $R/gpurun_out/${TAG}_excerpt.txt 2>&1
 python $R/profiles/kernel_stats.py $DB --by-grid gemm_mfma 40 > $R/gpurun_out/${TAG}_gemm_by_shape.txt
