@@ -566,13 +566,14 @@ __device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, i
 // widest mapping the 64-wide window admits is the fastest one.
 // Two phases in ONE window-sized LDS buffer: (1) the chase on the H window, every rotation logged (c, s: 24 bytes); H written
 // back; (2) the same buffer becomes U = I and the log is replayed onto it (bulge s's wave rotates its two columns, one barrier
-// per chain step).  With H and U side by side the kernel needed 133 KB of LDS and could only start on a CU with NO slab-update
-// workgroup on it -- and since the slab updates of the other iteration groups refill free slots at once, window launches
-// starved until those kernels drained.  At 85 KB it shares a CU with one slab-update workgroup (74 KB).
+// per chain step).  With H and U side by side the kernel needed 133 KB of LDS; now 66.5 KB + the log.  (The hope that a smaller
+// footprint would let window launches start next to the slab-update workgroups of the other iteration groups did not
+// materialise: a slab launch occupies every workgroup slot of the chip whatever is left of a CU's LDS -- DESIGN.md section 9.)
 constexpr int LPB = 64;                    // lanes per bulge
 constexpr int WTHREADS = QNS * LPB;        // threads of the window kernel
 constexpr int WIT = QW / LPB;              // element pairs per lane and phase
-constexpr int WMAXS = 48;                  // chain steps per launch (rotation log: WMAXS x QNS entries)
+constexpr int WMAXS = 96;                  // chain steps per launch (rotation log: WMAXS x QNS entries = 37 KB): the first window of a sweep
+                                           // chases 62 steps and the last one up to ~94, so no launch is split (48 split 7 % of them)
 template <class T> struct RotCS { T c; cx<T> s; };
 // DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it (it must stay within
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
@@ -1458,9 +1459,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         cx<T>* Ug = B.U + (long)G.b0 * QKC * QW * QW;
         const cx<T>* shg = B.shifts + (long)G.b0 * QKC * QNS;
         QrState* stg = B.st + G.b0;
-        // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary, + first / last window
-        // in up to two launches each), every further chain enters about 3 steps behind the one ahead
-        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 4 + 4 * (kc - 1) : 1;
+        // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary); every further chain
+        // enters about 3 steps behind the one ahead.  `bound` is one iteration old, i.e. already a step or so generous, and a sweep
+        // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
+        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
