@@ -12,7 +12,7 @@ python bench.py > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench_
 bash profiles/scripts/trace_bench.sh ${TAG}_bench_final
 cd $R
 for b in 16 32 64; do python bench.py --batch $b --steps 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_b$b.json; done
+python bench.py --precision native --steps 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_native.json
 python tests/gpu_gemm_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_gemm_shapes.txt
 timeout 300 python tests/gpu_config5.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_config5.log
 timeout 400 python tests/gpu_config3.py 21 32 32 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_config3.log
-python bench.py --precision native --steps 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_native.json

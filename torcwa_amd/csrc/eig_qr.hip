@@ -1375,8 +1375,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // Bulge chains per sweep.  Measured on MI355X (n = 1922): 2 / 3 chains cut the outer iterations by only 31 / 36 % (the AED's
     // deflation yield, not the shift count, paces the iteration) while the slab work grows by a third, and the two-launch
     // update they need costs 10 % on its own: 26.5 (1 chain, one launch) vs 22.1 / 21.9 solves/s at batch 128, 12.1 vs 11.3 at
-    // batch 16.  One chain is the default; the knob stays for other spectra.
-    const int kc = K.chains ? K.chains : 1;
+    // batch 16.  One chain is the default for batches; a single large matrix (the topology-optimisation case, n = 5202, batch 1) has
+    // no slab work to protect and gains from the shorter chain: 5.62 s (1 chain, AED 48) -> 5.16 s (3 chains) -> 4.79 s (3 chains,
+    // AED 64) for the whole forward solve (profiles/r02_single_matrix_knobs.txt).
+    const int kc = K.chains ? K.chains : (batch <= 2 ? QKC : 1);
     // software-pipelined slab kernel: knob slab_pipe = 2 switches it on.  Measured on MI355X at batch 128 it is NOT faster than the
     // one-strip-at-a-time kernel with dynamically claimed strips (27.4-28.0 vs 28.4 solves/s): a launch of the latter already
     // overlaps the loads of one wave with the MFMAs of its SIMD neighbour, and the static strips the pipeline needs bring back
@@ -1430,7 +1432,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // AED window: 64 deflates most per call (fewest sweeps, least slab work) but costs 3 ms of single-wave latency; at small
     // batches, where nothing is throughput bound, a smaller window shortens the chain
     const long mstride = (long)ngroups * n * n;              // distance between consecutive matrices of one group
-    const int aed_w = K.aed ? K.aed : (batch >= 64 ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48
+    const int aed_w = K.aed ? K.aed : ((batch >= 64 || batch <= 2) ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48; batch 1 with 3 chains: 64
     const size_t smp = smp_of(aed_w);
     // LAPACK skips the sweep when AED deflated more than 14 % of the window ("nibble") because there the sweep is the expensive
     // part.  Here the AED is, so every AED that leaves an active block is followed by a sweep in the same iteration.
