@@ -27,6 +27,7 @@ class Eig(torch.autograd.Function):
         `stable_eig_grad=False` branch of the reference (rcwa.py:1238, plain torch.linalg.eig); the choice is bound to the
         graph node at forward time, so no global is touched and concurrent solvers cannot disturb each other."""
         eng = Eig._eng()
+        ctx.eng = eng                         # the backward runs on the engine (device, stream) of its forward
         ctx.mode = mode
         ctx.nargs = 1 if mode is None else 2
         xb = x if x.dim() == 3 else x[None]
@@ -41,7 +42,7 @@ class Eig(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_eigval, grad_eigvec):
-        eng = Eig._eng()
+        eng = ctx.eng
         w, V = ctx.saved_tensors
         gw = grad_eigval if ctx.batched else grad_eigval[None]
         gV = grad_eigvec if ctx.batched else grad_eigvec[None]
