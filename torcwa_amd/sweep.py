@@ -144,7 +144,9 @@ def _run_spans(run, spans, streams, dev):
 def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
     """B sweep points of a 1-patterned-layer stack (configs 2 and 4 of BASELINE.json): freq [B], eps_grids [B,nx,ny].
 
-    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).
+    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).  At order [15,15]
+              (n = 1922) a point costs about 0.6 GB allocated / 0.8 GB reserved, so up to 256 points fit the 288 GB of an MI355X, and
+              larger chunks are faster (measured: 23.6 / 28.8 / 31.6 layer-solves/s at 64 / 128 / 256 points).
     streams : number of HIP streams / host threads the chunks are dealt to (default 1: on MI355X one stream was measured
               faster -- the QR window kernel needs 133 KB of LDS and evicts the slab workgroups of the other stream).
     """
