@@ -12,6 +12,8 @@ S-parameter read-out) over one batch of sweep points whose permittivity grids ar
                                                      # 128-lambda sweep split 8 ways) reported under "strong_scaling"
     python bench.py --gpus 8 --scaling strong        # only the split sweep (value = its throughput)
     python bench.py --gpus 8 --config 4              # configs[3]: 16x16x16 (Wx,Wy,lambda) sweep = 4096 solves, sharded (strong)
+    python bench.py --config 3                       # configs[2]: 4 patterned layers, order [21,21], 64-lambda sweep (4 layer-solves per point)
+    python bench.py --config 5                       # configs[4]: topology-optimisation step, order [25,25], complex128, forward + adjoint
 
 Under `python -m torch.distributed.run ... bench.py --gpus N ...` (the driver's launch) the ranks are already there and nothing
 is spawned.  No data-path collective exists: every rank solves its own contiguous block of the flattened sweep
@@ -52,11 +54,13 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4], help="BASELINE.json config: 2 = lambda sweep (configs[1]), 4 = (Wx,Wy,lambda) sweep (configs[3])")
-    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: weak for config 2, strong for config 4")
-    ap.add_argument("--batch", type=int, default=128, help="config 2: sweep points per GPU (weak) / in total (strong)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 2 = lambda sweep (configs[1]), 3 = 4-layer stack (configs[2]), 4 = (Wx,Wy,lambda) sweep (configs[3]), "
+                         "5 = forward + adjoint of one topology-optimisation step (configs[4]; N > 1: independent replicas)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: weak for configs 2, 3, 5, strong for config 4")
+    ap.add_argument("--batch", type=int, default=0, help="configs 2, 3: sweep points per GPU (weak) / in total (strong); 0 = 128 (config 2), 64 (config 3)")
     ap.add_argument("--points", type=int, default=4096, help="config 4: total sweep points (16^3 grid, cycled if larger)")
-    ap.add_argument("--order", type=int, default=15)
+    ap.add_argument("--order", type=int, default=0, help="Fourier order [o,o]; 0 = the config's own: 15 (2, 4), 21 (3), 25 (5)")
     ap.add_argument("--grid", type=int, default=300, help="permittivity grid is grid x grid")
     ap.add_argument("--chunk", type=int, default=0, help="points solved in lock-step (0 = min(local points, 128), config 4: min(local points, 256))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
@@ -66,7 +70,14 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-points", type=int, default=3, help="sweep points the CPU baseline times (>= 1)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--host-profile", action="store_true", help="cProfile of one extra (untimed) step, top entries to stderr")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.order <= 0:
+        args.order = {2: 15, 3: 21, 4: 15, 5: 25}[args.config]
+    if args.batch <= 0:
+        args.batch = {2: 128, 3: 64, 4: 128, 5: 1}[args.config]
+    if args.config == 5:
+        args.batch = 1
+    return args
 
 
 def spawn_ranks(args):
@@ -113,8 +124,61 @@ def make_inputs(config, idx, grid, device):
     return freq, grids.contiguous(), lam, eps_si
 
 
+def make_inputs_stack(idx, nl, grid, device):
+    """config 3 (Example1-1 style): four 200 nm layers, each the 180 x 100 nm a-Si:H rectangle rotated by 0 / 30 / 60 / 90 degrees in
+    SU-8 (n = 1.6), glass input half space; sweep point g -> the (g mod nl)-th of nl wavelengths spread over 400-700 nm."""
+    from torcwa_amd.sweep import asih_eps_table, rectangle_density
+    lam_t, eps_t = asih_eps_table()
+    k = np.linspace(0, len(lam_t) - 1, nl).round().astype(int)[idx % nl]
+    lam, eps_si = lam_t[k], eps_t[k]
+    eps_c = torch.as_tensor(eps_si, dtype=torch.complex64, device=device)
+    layers = []
+    for th in (0., 30., 60., 90.):
+        d = rectangle_density(grid, grid, 300., 300., 180., 100., 150., 150., theta=th / 180 * np.pi, dtype=torch.float32, device=device)
+        layers.append((200., (d[None] * eps_c[:, None, None] + (1. - d[None]) * 1.6 ** 2).contiguous()))
+    freq = torch.as_tensor(1.0 / lam, dtype=torch.float64, device=device)
+    return freq, layers, lam, eps_si
+
+
+def make_inputs_topopt(device):
+    """config 5 (Example6 style): a smooth random density on the 700 x 300 nm cell (700 x 300 grid, mirror-symmetric in y, Gaussian
+    blur of radius 20 via FFT like the notebook), silicon at 532 nm."""
+    nx, ny = 700, 300
+    rho = torch.rand(nx, ny, generator=torch.Generator().manual_seed(333), dtype=torch.float64)
+    rho = (rho + torch.flip(rho, dims=[1])) / 2
+    kx, ky = torch.fft.fftfreq(nx, d=1.0)[:, None], torch.fft.fftfreq(ny, d=1.0)[None, :]
+    blur = torch.exp(-2 * (np.pi * 20.0) ** 2 * (kx ** 2 + ky ** 2) / 4)
+    return torch.real(torch.fft.ifft2(torch.fft.fft2(rho) * blur)).clamp(0, 1).to(device)
+
+
+TOPOPT_EPS = 12.011610263133004 + 0.525912014756j
+_grad_norm = [None]
+
+
+def run_step_topopt(rho0, order, engine):
+    """One optimiser step of config 5: figure of merit (power into the +1 order, all four polarisation pairs) and its gradient with
+    respect to the density, through the stabilised eigendecomposition adjoint (torcwa/torch_eig.py)."""
+    import torcwa_amd
+    rho = rho0.clone().requires_grad_(True)
+    sim = torcwa_amd.rcwa(freq=1 / 532., order=order, L=[700., 300.], dtype=torch.complex128, device=rho0.device, stable_eig_grad=True, engine=engine)
+    sim.add_input_layer(eps=1.46 ** 2)
+    sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+    sim.add_layer(thickness=300., eps=rho * TOPOPT_EPS + (1. - rho))
+    sim.solve_global_smatrix()
+    t = [sim.S_parameters(orders=[1, 0], direction='forward', port='transmission', polarization=p, ref_order=[0, 0]) for p in ('xx', 'yx', 'xy', 'yy')]
+    fom = sum(torch.abs(v) ** 2 for v in t).sum()
+    fom.backward()
+    _grad_norm[0] = float(rho.grad.norm())
+    return fom.detach().to(torch.complex128).reshape(1, 1)
+
+
 def run_step(freq, grids, order, engine, args, chunk):
-    from torcwa_amd.sweep import solve_single_layer_sweep
+    from torcwa_amd.sweep import solve_single_layer_sweep, solve_stack_sweep
+    if args.config == 5:
+        return run_step_topopt(grids, order, engine)
+    if args.config == 3:
+        return solve_stack_sweep(freq, grids, order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64, precision=args.precision, engine=engine,
+                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False)
     return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
                                     precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False)
 
@@ -292,7 +356,10 @@ def main():
         engine = torcwa_amd.Engine(device=device)
     world = dist.get_world_size() if world > 1 else 1                          # the world size RCCL actually formed
 
-    scaling = args.scaling or ("weak" if args.config == 2 else "strong")
+    scaling = args.scaling or ("strong" if args.config == 4 else "weak")
+    if args.config == 5:
+        scaling = "weak"                                                            # replicas only: one optimisation step per GPU
+    layers_per_point = 4 if args.config == 3 else 1
     order = [args.order, args.order]
     n = 2 * (2 * args.order + 1) ** 2
 
@@ -312,10 +379,16 @@ def main():
 
     def measure(idx, steps, warmup, profile):
         """W untimed + K timed steps over this rank's sweep points `idx`; returns (elapsed max over ranks, last result, inputs)."""
-        freq, grids, lam, eps_si = make_inputs(args.config, idx, args.grid, device)
+        if args.config == 3:
+            freq, grids, lam, eps_si = make_inputs_stack(idx, args.batch, args.grid, device)
+        elif args.config == 5:
+            freq, grids, lam, eps_si = None, make_inputs_topopt(device), np.array([532.]), np.array([TOPOPT_EPS])
+        else:
+            freq, grids, lam, eps_si = make_inputs(args.config, idx, args.grid, device)
         # lock-step chunk: the 128-point sweep of config 2 is one chunk; the 512 points per GPU of config 4 go in chunks of 256
-        # (156 GB allocated / 208 GB reserved of the 288 GB; measured 31.6 vs 28.6 layer-solves/s with chunks of 128)
-        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), 128 if args.config == 2 else 256))
+        # (156 GB allocated / 208 GB reserved of the 288 GB; measured 31.6 vs 28.6 layer-solves/s with chunks of 128); the 4-layer
+        # stack of config 3 at n = 3698 in chunks of 32 (144 GiB peak)
+        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 32, 4: 256, 5: 1}[args.config]))
         out = None
         for w in range(warmup):
             try:
@@ -350,7 +423,7 @@ def main():
         return elapsed, out, (freq, grids, lam, eps_si, chunk)
 
     # ---- primary measurement ------------------------------------------------------------------------------------------
-    if args.config == 2:
+    if args.config in (2, 3, 5):
         total = args.batch * world if scaling == "weak" else args.batch
         idx = np.arange(rank * args.batch, (rank + 1) * args.batch) if scaling == "weak" else local_block(total)
     else:
@@ -365,7 +438,7 @@ def main():
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
-    roof = roofline(engine, args, elapsed, args.steps, n, len(idx)) if rank == 0 else None
+    roof = roofline(engine, args, elapsed, args.steps, n, len(idx) * layers_per_point) if rank == 0 else None
     if args.host_profile and rank == 0:
         import cProfile
         import pstats
@@ -376,7 +449,7 @@ def main():
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     full = gather_sweep(out, total) if world > 1 else out                 # the one collective of the job (RCCL all_gather, KB-sized)
-    value = total * args.steps / elapsed
+    value = total * layers_per_point * args.steps / elapsed
 
     # ---- strong-scaling leg (north_star: ">= 6x strong scaling of a wavelength sweep at 8 GPUs") ------------------------------
     strong = None
@@ -398,21 +471,31 @@ def main():
                    "device_mallocs_in_timed_region": ms1.get("segment.all.allocated", 0) - mstat["timed0"].get("segment.all.allocated", 0),
                    "device_frees_in_timed_region": ms1.get("segment.all.freed", 0) - mstat["timed0"].get("segment.all.freed", 0),
                    "alloc_retries": ms1.get("num_alloc_retries", 0)}
-        wl = ("configs[1]: single patterned layer, order=[%d,%d] (n=%d), %dx%d grid, %d-lambda sweep, glass input half-space"
-              % (args.order, args.order, n, args.grid, args.grid, args.batch)) if args.config == 2 else \
-             ("configs[3]: Example3-style (Wx,Wy,lambda) sweep, %d independent single-layer solves, order=[%d,%d] (n=%d), %dx%d grid, sharded by contiguous blocks"
-              % (total, args.order, args.order, n, args.grid, args.grid))
+        wl = {2: "configs[1]: single patterned layer, order=[%d,%d] (n=%d), %dx%d grid, %d-lambda sweep, glass input half-space"
+                 % (args.order, args.order, n, args.grid, args.grid, args.batch),
+              3: "configs[2]: Example1-1 style stack of 4 patterned layers (rotated rectangles in SU-8), order=[%d,%d] (n=%d), %dx%d grid, %d-lambda sweep "
+                 "(4 layer-solves + 3 dense layer-layer star products per point)" % (args.order, args.order, n, args.grid, args.grid, args.batch),
+              4: "configs[3]: Example3-style (Wx,Wy,lambda) sweep, %d independent single-layer solves, order=[%d,%d] (n=%d), %dx%d grid, sharded by contiguous blocks"
+                 % (total, args.order, args.order, n, args.grid, args.grid),
+              5: "configs[4]: Example6-style topology-optimisation step, order=[%d,%d] (n=%d), 700x300 grid, complex128: forward + adjoint (stabilised eig "
+                 "gradient) of one patterned layer = one layer-solve; N > 1: independent replicas" % (args.order, args.order, n)}[args.config]
         res = {
             "metric": "RCWA layer-solves/sec (complex64 I/O) at Fourier order [%d,%d]" % (args.order, args.order),
             "value": value, "unit": "layer-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "c128 arithmetic (fp64 MFMA; complex64 I/O)" if args.precision == "high" else "c64",
+            "dtype": "c128" if args.config == 5 else ("c128 arithmetic (fp64 MFMA; complex64 I/O)" if args.precision == "high" else "c64"),
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
-            "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "chunk": int(chunk), "streams": args.streams,
+            "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
+                       "chunk": int(chunk), "streams": args.streams,
                        "precision": args.precision, "backend": ("gloo" if EMU else "nccl (RCCL)") if world > 1 else None},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "gathered_points": int(full.shape[0]),
             "numerical_failures": 0, "hbm": mem, "csrc_sha16": csrc_sha16(),
         }
+        if args.config == 5 and roof is not None:
+            roof["layer_solve"]["note"] = "t_measured covers forward AND adjoint; T_roof prices the forward solve only"
+        if args.config == 5:
+            res["metric"] = "RCWA layer-solves/sec, forward + adjoint (complex128) at Fourier order [%d,%d]" % (args.order, args.order)
+            res["fom"], res["grad_norm"] = float(full[0, 0].real), _grad_norm[0]
         if strong is not None:
             res["strong_scaling"] = strong
         res["roofline"] = roof

@@ -48,3 +48,17 @@ def test_bench_config4_strong_sharded():
     r1 = _bench("--config", "4", "--points", "5", gpus=1)
     assert np.allclose(r1["txx00_sample"], r["txx00_sample"], rtol=1e-6)
     assert abs(r1["value"]) > 0
+
+
+def test_bench_config3_stack_and_config5_adjoint():
+    """The 4-layer stack (configs[2]: 4 layer-solves per sweep point, ragged chunks) and the forward + adjoint step (configs[4]:
+    replicas at N > 1) run through the same launcher and JSON contract."""
+    r = _bench("--config", "3", "--batch", "3", "--chunk", "2")
+    assert "configs[2]" in r["config"]["workload"] and r["config"]["layer_solves_per_point"] == 4 and r["gathered_points"] == 3
+    assert r["scaling"] == "weak" and r["value"] > 0
+    assert abs(r["value"] * r["ms_per_step"] / 1e3 - 12) < 1e-6                  # 3 points x 4 layers per step
+    one = _bench("--config", "5")
+    two = _bench("--config", "5", gpus=2)
+    assert "configs[4]" in one["config"]["workload"] and one["dtype"] == "c128" and one["gathered_points"] == 1 and two["gathered_points"] == 2
+    assert one["fom"] > 0 and one["grad_norm"] > 0 and np.isclose(one["fom"], two["fom"], rtol=1e-9)
+    assert "forward + adjoint" in one["metric"]
