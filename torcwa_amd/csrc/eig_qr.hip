@@ -876,7 +876,14 @@ __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, con
 // 3M variant of one K half for the tile pair (2 pp, 2 pp + 1): three real MFMAs per k-step and tile (mfma.hpp).
 //   right update (C = X U):    P1 += xr ur,  P2 += xi ui,  P3 += (xr + xi)(ur + ui);   Cr = P1 - P2,  Ci = P3 - P1 - P2
 //   left update  (C = U^H X):  P1 += ur xr,  P2 += ui xi,  P3 += (ur - ui)(xr + xi);   Cr = P1 + P2,  Ci = P3 - P1 + P2
-template <class T, int SIDE>
+//
+// BAND: the unitary of a chain step is a product of at most QNS bulge passes, each an ascending sequence of adjacent-column
+// rotations, i.e. an upper Hessenberg matrix (rotations of different bulges that are interleaved in time act two or more columns apart
+// and commute into that order): U has at most QNS = 16 nonzero subdiagonals.  With 16-wide k chunks c and 16-wide output tiles t
+// (t indexes the COLUMNS of U on either side) the block (c, t) is structurally zero for c >= t + 2 -- (2,0), (3,0), (3,1): 3 of the
+// 16 blocks, 19 % of the matrix-core work.  The conditions fold at compile time (h, pp, cc, q are unrolled constants); whether a
+// given U has the band is decided by the kernel when it stages U into LDS (dense AED / small-block unitaries use the same kernel).
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int pp, int lane, const cx<T> (&x)[8],
                                                       typename Mfma<T>::acc_t (&p1)[2], typename Mfma<T>::acc_t (&p2)[2], typename Mfma<T>::acc_t (&p3)[2]) {
     const int lr = lane & 15, lk = lane >> 4;
@@ -884,29 +891,33 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int chunk = 2 * h + cc;
+            const bool use0 = !(BAND && chunk >= 2 * pp + 2), use1 = !(BAND && chunk >= 2 * pp + 3);       // tiles 2pp, 2pp + 1
+            if (!use0 && !use1) continue;
             const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 32 * pp;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
             const T xs = xr + xi;
             T ur[2], ui[2], us[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if (!(q == 0 ? use0 : use1)) continue;
                 ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
                 us[q] = SIDE == 1 ? ur[q] + ui[q] : ur[q] - ui[q];
             }
             if (SIDE == 1) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(xr, ur[q], p1[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p1[q] = Mfma<T>::mma(xr, ur[q], p1[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(xi, ui[q], p2[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p2[q] = Mfma<T>::mma(xi, ui[q], p2[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(xs, us[q], p3[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p3[q] = Mfma<T>::mma(xs, us[q], p3[q]);
             } else {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(ur[q], xr, p1[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p1[q] = Mfma<T>::mma(ur[q], xr, p1[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(ui[q], xi, p2[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p2[q] = Mfma<T>::mma(ui[q], xi, p2[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
             }
             // bound the hoisting of the U fragment reads to the next two k-steps: unbounded, hipcc keeps the fragments of a whole K half
             // live (96 registers), which the register double buffer of the streamed operand has no room for
@@ -970,21 +981,21 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
     }
 }
 
-template <class T, int SIDE, bool FULL = false>
+template <class T, int SIDE, bool FULL = false, bool BAND = false>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]);
 
-template <class T, int SIDE>
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane) {
     cx<T> xa[8], xb[8];
     slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
     slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
-    slab_compute<T, SIDE>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+    slab_compute<T, SIDE, false, BAND>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
 }
 
 // multiply + store of one strip whose streamed operand is already in (or on its way to) registers
-template <class T, int SIDE, bool FULL>
+template <class T, int SIDE, bool FULL, bool BAND>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
     if constexpr (sizeof(T) == 8) {
@@ -998,8 +1009,8 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { p1[q][r] = T(0); p2[q][r] = T(0); p3[q][r] = T(0); }
-            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 0, pp, lane, xa, p1, p2, p3);
-            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 1, pp, lane, xb, p1, p2, p3);
+            slab_multiply_half_3m<T, SIDE, BAND>(Ur, Ui, 0, pp, lane, xa, p1, p2, p3);
+            slab_multiply_half_3m<T, SIDE, BAND>(Ur, Ui, 1, pp, lane, xb, p1, p2, p3);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1060,7 +1071,7 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                            QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work, int nslab, int dynamic) {
+                                                           unsigned* __restrict__ work, int nslab, int dynamic, int band_on) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1079,13 +1090,18 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
         atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
     const cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    int dense = 0;                            // any nonzero in the blocks the banded product skips?
     for (int e = t; e < QW * QW; e += 256) {
         const int k = e >> 6, c = e & 63;
         cx<T> u(T(0), T(0));
         if (k < ww && c < ww) u = U[k * QW + c];
         Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
     }
+    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);          // [4] per-wave votes, behind the planes
+    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
     __syncthreads();
+    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
     cx<T>* H = Aall + (long)b * mstride;
     cx<T>* Z = Zall + (long)b * mstride;
     if (PART == 2 && dynamic) {
@@ -1099,8 +1115,13 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         for (int g = claim(); g < S;) {
             const int gn = claim();
             const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
-            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            if (band) {
+                if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+                else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+            } else {
+                if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+                else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            }
             g = gn;
         }
         return;
@@ -1109,8 +1130,14 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         const int g = g0 + wave + 4 * i;
         if (g >= S) break;
         const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
-        if (PART == 0 || (PART == 2 && d.side == 0)) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-        else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        const bool left = PART == 0 || (PART == 2 && d.side == 0);
+        if (band) {
+            if (left) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+        } else {
+            if (left) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        }
     }
 }
 
@@ -1263,7 +1290,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1285,6 +1312,7 @@ static QrKnobs& qr_knobs() {
         q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
+        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1338,6 +1366,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_dyn") { slot = &k.dyn; hi = 2; }
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
+    else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1350,7 +1379,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
     const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
-    const size_t sma = sizeof(T) * 2 * QW * MLD;
+    const size_t sma = sizeof(T) * 2 * QW * MLD + 16;        // + the four per-wave band votes
     auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
     static std::once_flag attr_once[2];
     int attr_rc = 0;
@@ -1384,6 +1413,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // overlaps the loads of one wave with the MFMAs of its SIMD neighbour, and the static strips the pipeline needs bring back
     // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
     const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
+    const int band_on = K.band != 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1486,18 +1516,18 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               if (kc == 1 && dyn && pipe) {
                   if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk);
               } else if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } }
         }
     };
