@@ -75,7 +75,9 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  * variables TRX_QR_GROUPS / TRX_SLAB_SPW / TRX_QR_AED / TRX_QR_NIBBLE / TRX_QR_MOVES / TRX_QR_CHAINS are read ONCE per process as
  * initial values.  key: "qr_groups" (iteration groups, 1-8), "slab_spw" (strips per wave of the off-window update: 1, 2, 4),
  * "qr_aed" (AED window, 16-64), "qr_nibble" (0-100), "qr_moves" (AED reordering bound), "qr_chains" (bulge chains per sweep, 1-3),
- * "slab_band" (1 = dense window unitary always; default: the off-window update skips the structurally zero blocks of a chain unitary);
+ * "slab_band" (1 = dense window unitary always; default: the off-window update skips the structurally zero blocks of a chain unitary),
+ * "lu_split" (LU panels of 1-2 matrices are factored by several workgroups per matrix while at least this many rows remain; 0 = 1024,
+ * 1 = never);
  * value 0 = automatic.  Results do not depend on any of them (tests/test_eig.py).  Returns TRX_OK or TRX_ERR_ARG. */
 int trx_tuning(const char* key, int value);
 
