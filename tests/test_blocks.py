@@ -214,7 +214,7 @@ def test_hmodes_structured(backend, dtype, tol):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
-@pytest.mark.parametrize("n,batch", [(200, 1), (333, 2), (530, 1)])
+@pytest.mark.parametrize("n,batch", [(200, 1), (333, 2), (530, 1), (300, 9)])
 def test_lu_row_split_panel(backend, dtype, tol, n, batch):
     """The row-split panel (few large matrices: W workgroups per matrix, one launch per panel column, implicit pivoting inside the
     panel) against numpy, and against the one-workgroup panel: same pivots (no exact ties in random data), same factors."""
@@ -225,13 +225,14 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
     B = crand((batch, n, 9), dtype)
     res = []
     for split in (128, 1):          # 128: split while >= 128 rows remain; 1: never
-        assert be.lib.tuning(b"lu_split", split) == 0
+        assert be.lib.tuning(b"lu_split", split) == 0 and be.lib.tuning(b"lu_split_batch", 16) == 0
         try:
             dA, dB = be.dev(A), be.dev(B)
             piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
             rc = be.lib.lu_solve(dtcode(dtype), be.ptr(dA), n, be.ptr(dB), 9, batch, be.ptr(piv), be.ptr(info), be.stream)
         finally:
             be.lib.tuning(b"lu_split", 0)
+            be.lib.tuning(b"lu_split_batch", 0)
         assert rc == 0 and (be.host(info) == 0).all()
         res.append((be.host(dA), be.host(dB), be.host(piv)))
     X = np.linalg.solve(A.astype(np.complex128), B.astype(np.complex128))

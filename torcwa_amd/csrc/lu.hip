@@ -394,9 +394,13 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 constexpr int NBO = 8 * NB;
 
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
+static int g_lu_split_batch = 0;          // 0 = automatic (2): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
 int lu_set_knob(const char* key, int value) {
-    if (std::string(key) != "lu_split" || value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
-    g_lu_split_rows = value;
+    const std::string k(key);
+    if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
+    if (k == "lu_split") g_lu_split_rows = value;
+    else if (k == "lu_split_batch") g_lu_split_batch = value;
+    else return TRX_ERR_ARG;
     return TRX_OK;
 }
 
@@ -415,9 +419,13 @@ int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int ba
             // few large matrices: row-split panel (see above); needs 2 W ints of the pivot array's unwritten tail
             const int rows = n - c0;
             const int split_min = g_lu_split_rows ? g_lu_split_rows : 1024;
+            // workgroups per matrix: about 512 per launch over the batch, at least 64 rows each (a larger batch already supplies
+            // workgroups, but the one-workgroup panel still leaves half of the CUs idle at batch 128: knob lu_split_batch)
+            const int split_batch = g_lu_split_batch ? g_lu_split_batch : 2;
             int W = rows / 64 < LSW_MAX ? rows / 64 : LSW_MAX;
-            if (W > LST) W = LST;
-            if (batch <= 2 && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
+            const int wcap = 512 / batch > 2 ? 512 / batch : 2;
+            if (W > wcap) W = wcap;
+            if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
                 ProfScope prof(PROF_LU_PANEL, s, 0, 0);
                 TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
                 for (int j = 0; j < jb; ++j)
