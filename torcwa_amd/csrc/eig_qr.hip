@@ -579,7 +579,7 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr, int look = 0) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
@@ -593,8 +593,14 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
     // positions go to the [par] copy, which nobody writes in this step.
-    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
-    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) st_all[b].mode = QR_CHASE; return; }                  // this slot applies the AED unitary
+    // look-ahead schedule: publish what the update kernels of THIS step read, under the step's parity (they run while the next step,
+    // of the other parity, is chased).  A slot that applies a unitary of the prepare kernel has no next window: nothing is critical.
+    auto publish = [&](int pw0, int pw1, int gc, int slot) {
+        QrState& g = st_all[b];
+        g.lw0[par] = pw0; g.lw1[par] = pw1; g.lgc[par] = gc; g.lus[par] = slot; g.lstrip[par] = 0;
+    };
+    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) { st_all[b].mode = QR_SMALL_APPLIED; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }      // this slot applies the block's unitary
+    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) { st_all[b].mode = QR_CHASE; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }                  // this slot applies the AED unitary
     const int tau0 = st.tau[ch][par];
     bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
     const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
@@ -614,6 +620,9 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (t == 0) {
             if (st.w0[ch] != 0 || st.w1[ch] != 0) { st_all[b].w0[ch] = 0; st_all[b].w1[ch] = 0; }
             st_all[b].tau[ch][par ^ 1] = tau0;
+            // nothing new to apply in this step.  (With the look-ahead schedule the update kernels of a step read the parity copy: an
+            // idle, finished or small-block-applied matrix must not see the window its previous step of this parity left there.)
+            if (look) publish(0, 0, 0, 0);
         }
         return;
     }
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
     }
     if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
-    cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    cx<T>* U = Uall + ((long)b * QKC + (look ? 1 + par : ch)) * QW * QW;      // look-ahead (one chain): chain slots 1, 2 double-buffer the step's unitary
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
     {
         // phase 1 done: the window goes back to H, the buffer becomes U = I
@@ -751,7 +760,19 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             }
         }
     }
-    if (t == 0) { st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1; }
+    if (t == 0) {
+        st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1;
+        if (look) {
+            // columns right of this window that the next window covers: their left update is the critical part of this step
+            int gc = 0;
+            if (tau_end + 1 <= st.tau_last[ch]) {
+                int n0, n1, ne;
+                chain_window(ilo, ihi, k, tau_end + 1, st.tau_last[ch], n0, n1, ne);
+                if (n1 > w1) gc = (n1 - w1 + 15) >> 4;
+            }
+            publish(w0, w1, gc, 1 + par);
+        }
+    }
     if (dbg) dbg[14] += clock64() - tk0;
 }
 
@@ -1141,6 +1162,74 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     }
 }
 
+// Off-window update of one step of the LOOK-AHEAD schedule (knob qr_look; one chain per sweep).  The update of step k is cut in two:
+//   phase 0 ("critical")  the first lgc left strips = the columns right of window k that window k+1 covers.  It runs on the group's
+//                         main stream between the two chases (after the remaining update of step k-1, whose rows it shares).
+//   phase 1 ("remaining") all other left strips, the right strips of H and the strips of Z, on the group's SECOND stream, while
+//                         window k+1 is chased: it touches nothing of window k+1 (rows >= w0(k+1) only in columns >= w1(k+1)).
+// Ordering (host side, events): chase k -> critical k -> chase k+1;  remaining k after critical k and remaining k-1;  critical k+1
+// after remaining k.  Everything a step's kernels read (window, U slot, strip counter) sits under the step's parity in QrState, the
+// chase of the next step writes the other parity.  Strips of the remaining update are claimed dynamically.
+template <class T>
+__global__ __launch_bounds__(256, 2) void apply_look_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+                                                         QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
+                                                         unsigned* __restrict__ work, int par, int phase, int band_on) {
+    TRX_DYN_SMEM(smem);
+    T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
+    T* Ui = Ur + QW * MLD;
+    const int b = blockIdx.y;
+    const int w0 = st_all[b].lw0[par], w1 = st_all[b].lw1[par];
+    const int ww = w1 - w0;
+    if (ww <= 0) return;
+    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
+    int gc = st_all[b].lgc[par];
+    if (gc > nL) gc = nL;
+    const int S = phase == 0 ? gc : nL - gc + nR + nZ;
+    if (phase == 0 ? (int)blockIdx.x * 4 >= S : *(volatile int*)&st_all[b].lstrip[par] >= S) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (phase == 1 && blockIdx.x == 0 && t == 0) atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
+    const cx<T>* U = Uall + ((long)b * QKC + st_all[b].lus[par]) * QW * QW;
+    int dense = 0;
+    for (int e = t; e < QW * QW; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        cx<T> u(T(0), T(0));
+        if (k < ww && c < ww) u = U[k * QW + c];
+        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
+    }
+    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);
+    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
+    __syncthreads();
+    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
+    cx<T>* H = Aall + (long)b * mstride;
+    cx<T>* Z = Zall + (long)b * mstride;
+    auto run = [&](int g) {              // strip g of the step's full list: left | right-H | Z
+        const SlabStrip<T> d = slab_locate<T, 2>(g, nL, nR, H, Z, n, w0, w1);
+        if (band) {
+            if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+        } else {
+            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        }
+    };
+    if (phase == 0) {
+        for (int g = blockIdx.x * 4 + wave; g < S; g += 4 * gridDim.x) run(g);
+        return;
+    }
+    auto claim = [&]() {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&st_all[b].lstrip[par], 1);
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    for (int g = claim(); g < S;) {
+        const int gn = claim();
+        run(g + gc);
+        g = gn;
+    }
+}
+
 // One 16x16 output tile (tile q of the strip) with the 3M product over the full K = QW, then its store: the unit of work of the
 // software-pipelined kernel below.  A single tile keeps only 24 accumulator registers live next to the two 64-register operand
 // buffers; the streamed operand is reused from registers by all four tiles, the U fragments come from LDS per tile.
@@ -1290,7 +1379,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, look = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1312,7 +1401,8 @@ static QrKnobs& qr_knobs() {
         q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
-        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
+        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);
+        q.look = geti("TRX_QR_LOOK", 0, 3, 0);                // 2: look-ahead schedule (off-window update of step k under the chase of step k+1)              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1328,7 +1418,16 @@ struct QrLane {
     int* hsum = nullptr;               // pinned host memory, 2 x 4 ints
     int dev = -1;
     bool has_stream = false;
+    hipStream_t s2 = nullptr;          // look-ahead schedule: the stream of the remaining updates (created on first use)
+    hipEvent_t evA[2] = {nullptr, nullptr}, evR[2] = {nullptr, nullptr};   // "critical update of step k done" / "remaining update of step k done", k % 2
 };
+static bool lane_look_ready(QrLane& l) {
+    if (l.s2) return true;
+    if (hipStreamCreateWithFlags(&l.s2, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&l.evA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.evR[i], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
@@ -1367,6 +1466,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
+    else if (s == "qr_look") { slot = &k.look; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1388,7 +1488,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) || set_max_dyn_smem((const void*)apply_look_kernel<T>, sma) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp_of(SM));
     });
     if (attr_rc) return TRX_ERR_LAUNCH;
@@ -1414,6 +1514,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
     const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
     const int band_on = K.band != 1;
+    // look-ahead schedule (one chain per sweep): see apply_look_kernel.  Opt-in (knob qr_look = 2) until it is measured.
+    const bool look = K.look >= 2 && kc == 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1431,6 +1533,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
+        bool have_r;           // look-ahead: a remaining update has been queued on the second stream
     };
     // 4 groups = the number of hardware queues a HIP process gets by default; beyond that streams share queues and serialise
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
@@ -1454,7 +1557,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.work = 0;
         G.par = 0;
         G.g = g;
+        G.have_r = false;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
+        if (look && !lane_look_ready(G.lane)) { rc = TRX_ERR_LAUNCH; ++nlanes; break; }
         ++nlanes;
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
@@ -1496,10 +1601,50 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
         const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
+        if (look) {
+            // chase k -> critical k -> chase k+1 on the group's stream; remaining k on the second stream (after critical k, before
+            // critical k+1); the prepare kernel that follows the sweep waits for the last remaining update
+            int wgm = (K.wgs ? K.wgs : 448) / G.nb;          // < 2 per CU over the group: the chase of the next step needs CUs of its own
+            wgm = wgm < 1 ? 1 : (wgm > 32 ? 32 : wgm);
+            if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
+            hipStream_t s2 = G.lane.s2;
+            auto remaining = [&](int par) {
+                (void)hipStreamWaitEvent(s2, G.lane.evA[par], 0);
+                { ProfScope p(PROF_QR_APPLY_RIGHT, s2, 0, 0);
+                  TRX_LAUNCH((apply_look_kernel<T>), dim3(wgm, G.nb), dim3(256), sma, s2, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 1, band_on); }
+                (void)hipEventRecord(G.lane.evR[par], s2);
+                G.have_r = true;
+            };
+            // qr_look = 3 (tests): the remaining update of step k is ISSUED after the chase of step k+1 instead of before it -- an
+            // order the events allow just as well.  On the in-order CPU emulator the two issue orders are the two extreme
+            // interleavings of "remaining k" with "chase k+1", so equal results there check that the two really are independent.
+            const bool defer = K.look == 3;
+            int pending = -1;
+            for (int q = 0; q < nwin; ++q) {
+                const int par = G.par;
+                { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
+                  TRX_LAUNCH((qr_window_kernel<T, false>), dim3(1, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, par, (long long*)nullptr, 1); }
+                if (pending >= 0) { remaining(pending); pending = -1; }
+                if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[par ^ 1], 0);
+                TRX_LAUNCH((apply_look_kernel<T>), dim3(1, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 0, band_on);
+                (void)hipEventRecord(G.lane.evA[par], G.s);
+                if (q == 0) {
+                    // the first slot of a sweep applies the unitary of the prepare kernel (AED window / finished small block) where
+                    // there is one: its rows and columns are not related to the first chase window, so nothing of it may overlap
+                    remaining(par);
+                    (void)hipStreamWaitEvent(G.s, G.lane.evR[par], 0);
+                } else if (defer) pending = par;
+                else remaining(par);
+                G.par ^= 1;
+            }
+            if (pending >= 0) remaining(pending);
+            if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[G.par ^ 1], 0);
+            return;
+        }
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev, 0);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr, 0); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
