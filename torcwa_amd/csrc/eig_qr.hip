@@ -579,14 +579,14 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr, int look = 0) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr, int look = 0, int wmax = WMAXS) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
     RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
-    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
+    QrState& sst = *reinterpret_cast<QrState*>(rlog + wmax * QNS);        // wmax <= WMAXS: chain steps per launch (sizes the log)
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
     __syncthreads();
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     int w0 = 0, w1 = 0, tau_end = 0;
     if (move) {
         chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
-        if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several launches
+        if (tau_end > tau0 + wmax - 1) tau_end = tau0 + wmax - 1;      // first and last window of a sweep: several launches
         if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
             // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
             // this step); this chain may only work strictly above it
@@ -1516,6 +1516,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const int band_on = K.band != 1;
     // look-ahead schedule (one chain per sweep): see apply_look_kernel.  Opt-in (knob qr_look = 2) until it is measured.
     const bool look = K.look >= 2 && kc == 1;
+    // A chase workgroup of the look-ahead schedule has to find room on a CU that also holds ONE slab-update workgroup (74 KB of
+    // the 160 KB): with a rotation log of 48 instead of 96 chain steps it needs 85 KB instead of 104 KB.  The first window of a
+    // sweep (62 steps) and a clipped last one then take two launches.
+    const int wmax_look = 48;
+    const size_t smw_look = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * wmax_look * QNS + sizeof(QrState);
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1599,7 +1604,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary); every further chain
         // enters about 3 steps behind the one ahead.  `bound` is one iteration old, i.e. already a step or so generous, and a sweep
         // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
-        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
+        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) + (look ? 2 : 0) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
         if (look) {
             // chase k -> critical k -> chase k+1 on the group's stream; remaining k on the second stream (after critical k, before
@@ -1623,7 +1628,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             for (int q = 0; q < nwin; ++q) {
                 const int par = G.par;
                 { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-                  TRX_LAUNCH((qr_window_kernel<T, false>), dim3(1, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, par, (long long*)nullptr, 1); }
+                  TRX_LAUNCH((qr_window_kernel<T, false>), dim3(1, G.nb), dim3(WTHREADS), smw_look, G.s, Ag, mstride, n, stg, Ug, shg, par, (long long*)nullptr, 1, wmax_look); }
                 if (pending >= 0) { remaining(pending); pending = -1; }
                 if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[par ^ 1], 0);
                 TRX_LAUNCH((apply_look_kernel<T>), dim3(1, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 0, band_on);
@@ -1643,8 +1648,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         }
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev, 0);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr, 0); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev, 0, WMAXS);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr, 0, WMAXS); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
