@@ -74,7 +74,11 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
 /* Tuning knobs of the QR phase of trx_eig (no reference counterpart).  Defaults are chosen from the batch size; the environment
  * variables TRX_QR_GROUPS / TRX_SLAB_SPW / TRX_QR_AED / TRX_QR_NIBBLE / TRX_QR_MOVES / TRX_QR_CHAINS are read ONCE per process as
  * initial values.  key: "qr_groups" (iteration groups, 1-8), "slab_spw" (strips per wave of the off-window update: 1, 2, 4),
- * "qr_aed" (AED window, 16-64), "qr_nibble" (0-100), "qr_moves" (AED reordering bound), "qr_chains" (bulge chains per sweep, 1-3);
+ * "qr_aed" (AED window, 16-64), "qr_nibble" (0-100), "qr_moves" (AED reordering bound), "qr_chains" (bulge chains per sweep, 1-3),
+ * "slab_band" (1 = dense window unitary always; default: the off-window update skips the structurally zero blocks of a chain unitary),
+ * "lu_split" (LU panels of 1-2 matrices are factored by several workgroups per matrix while at least this many rows remain; 0 = 1024,
+ * 1 = never), "lu_split_batch" (largest batch that uses it; 0 = 2), "qr_look" (2 = look-ahead schedule of the QR sweeps: the off-window
+ * update of window step k runs on a second stream while step k+1 is chased; 3 = the same with the other legal issue order, for tests);
  * value 0 = automatic.  Results do not depend on any of them (tests/test_eig.py).  Returns TRX_OK or TRX_ERR_ARG. */
 int trx_tuning(const char* key, int value);
 

@@ -210,3 +210,49 @@ def test_hmodes_structured(backend, dtype, tol):
         P = np.block([[Z, M], [-M, Z]]) + np.vstack((Kx, Ky)) @ np.linalg.inv(E[b].astype(np.complex128)) @ np.hstack((Ky, -Kx))
         ref = np.linalg.solve(P, W[b].astype(np.complex128) * kz[b].astype(np.complex128)[None, :])
         assert np.abs(be.host(V)[b] - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
+@pytest.mark.parametrize("n,batch", [(200, 1), (333, 2), (530, 1), (300, 9)])
+def test_lu_row_split_panel(backend, dtype, tol, n, batch):
+    """The row-split panel (few large matrices: W workgroups per matrix, one launch per panel column, implicit pivoting inside the
+    panel) against numpy, and against the one-workgroup panel: same pivots (no exact ties in random data), same factors."""
+    be = get_backend(backend)
+    A = crand((batch, n, n), dtype)
+    A[0, :, 0] *= 1e-3
+    A[0, 7, :] *= 50.0              # a row that wins several pivot searches in a row
+    B = crand((batch, n, 9), dtype)
+    res = []
+    for split in (128, 1):          # 128: split while >= 128 rows remain; 1: never
+        assert be.lib.tuning(b"lu_split", split) == 0 and be.lib.tuning(b"lu_split_batch", 16) == 0
+        try:
+            dA, dB = be.dev(A), be.dev(B)
+            piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+            rc = be.lib.lu_solve(dtcode(dtype), be.ptr(dA), n, be.ptr(dB), 9, batch, be.ptr(piv), be.ptr(info), be.stream)
+        finally:
+            be.lib.tuning(b"lu_split", 0)
+            be.lib.tuning(b"lu_split_batch", 0)
+        assert rc == 0 and (be.host(info) == 0).all()
+        res.append((be.host(dA), be.host(dB), be.host(piv)))
+    X = np.linalg.solve(A.astype(np.complex128), B.astype(np.complex128))
+    for LU, Xg, piv in res:
+        assert np.abs(Xg - X).max() / np.abs(X).max() < tol
+    assert (res[0][2] == res[1][2]).all()
+    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < (1e-13 if dtype == np.complex128 else 1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_lu_row_split_singular_info(backend):
+    be = get_backend(backend)
+    n = 300
+    A = crand((1, n, n), np.complex128)
+    A[0, :, 5] = 0.0
+    dA, dB = be.dev(A), be.dev(crand((1, n, 2), np.complex128))
+    piv, info = be.empty((1, n), np.int32), be.empty((1,), np.int32)
+    assert be.lib.tuning(b"lu_split", 128) == 0
+    try:
+        assert be.lib.lu_solve(1, be.ptr(dA), n, be.ptr(dB), 2, 1, be.ptr(piv), be.ptr(info), be.stream) == 0
+    finally:
+        be.lib.tuning(b"lu_split", 0)
+    assert be.host(info)[0] == 6

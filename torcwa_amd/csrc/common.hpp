@@ -139,6 +139,7 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
 
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);
+int lu_set_knob(const char* key, int value);          // trx_tuning("lu_split", rows)
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);

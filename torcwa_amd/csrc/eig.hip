@@ -158,7 +158,8 @@ extern "C" int trx_eig_backward(int dtype, const void* w, const void* V, const v
 
 extern "C" int trx_tuning(const char* key, int value) {
     if (!key) return TRX_ERR_ARG;
-    return trx::qr_set_knob(key, value);
+    const int rc = trx::qr_set_knob(key, value);
+    return rc == TRX_OK ? rc : trx::lu_set_knob(key, value);
 }
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {

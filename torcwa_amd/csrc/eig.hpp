@@ -27,6 +27,12 @@ struct QrState {
     int w0[EigPlan::QKC], w1[EigPlan::QKC];   // window of each chain's last step: its pending off-window update acts on [w0, w1)
     int fail;                     // number of unconverged eigenvalues on failure
     int strip_next;               // next unclaimed strip of the pending off-window update (dynamic strip scheduling; reset per window step)
+    // look-ahead schedule (knob qr_look, one chain): the off-window update of window step k runs on a second stream while step k+1
+    // is chased, so what it reads is double-buffered by the parity of the step
+    int lw0[2], lw1[2];           // window of the step
+    int lgc[2];                   // left strips (16 columns) right of the window that the NEXT window needs: updated first ("critical")
+    int lus[2];                   // slot of U that holds the step's unitary (0: written by the prepare kernel, 1 + parity: by the chase)
+    int lstrip[2];                // dynamic strip counter of the step's remaining update
 };
 enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
 

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall,
 
 // Yraw[r, c] = sum_{q>j} A[r, q] * V[q, c]   for r in [r0, n)
 template <class T>
-__global__ __launch_bounds__(256) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c,
+__global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c,
                                                          const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, int rows_per_block) {
     TRX_DYN_SMEM(smem);
     cx<T>* v = reinterpret_cast<cx<T>*>(smem);        // [n - j - 1]
@@ -235,10 +235,14 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
               TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau); }
             if (c < ib) {
                 const int j = p0 + c;
-                const int rpb = 64;
+                // 64 rows per 4-wave workgroup fill the chip when the batch supplies the workgroups (batch 128 at n = 1922: 3840); one or
+                // two large matrices do not (n = 5202, batch 1: 82 workgroups on 256 CUs, and 83 KB of LDS for v leaves room for one
+                // workgroup per CU): there 16 rows per 8-wave workgroup give 4x the workgroups and twice the waves per CU
+                const bool few = (long)cdiv_i(nr, 64) * batch < 256;
+                const int rpb = few ? 16 : 64, gthreads = few ? 512 : 256;
                 // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
                 ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
-                TRX_LAUNCH((hess_gemv_kernel<T>), dim3(cdiv_i(nr, rpb), batch), dim3(256), sizeof(cx<T>) * (size_t)(n - j - 1), s,
+                TRX_LAUNCH((hess_gemv_kernel<T>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
                            (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
             }
         }

@@ -579,29 +579,35 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr, int look = 0, int wmax = WMAXS) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
     RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
-    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
+    QrState& sst = *reinterpret_cast<QrState*>(rlog + wmax * QNS);        // wmax <= WMAXS: chain steps per launch (sizes the log)
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
     __syncthreads();
     const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
     // positions go to the [par] copy, which nobody writes in this step.
-    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
-    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) st_all[b].mode = QR_CHASE; return; }                  // this slot applies the AED unitary
+    // look-ahead schedule: publish what the update kernels of THIS step read, under the step's parity (they run while the next step,
+    // of the other parity, is chased).  A slot that applies a unitary of the prepare kernel has no next window: nothing is critical.
+    auto publish = [&](int pw0, int pw1, int gc, int slot) {
+        QrState& g = st_all[b];
+        g.lw0[par] = pw0; g.lw1[par] = pw1; g.lgc[par] = gc; g.lus[par] = slot; g.lstrip[par] = 0;
+    };
+    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) { st_all[b].mode = QR_SMALL_APPLIED; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }      // this slot applies the block's unitary
+    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) { st_all[b].mode = QR_CHASE; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }                  // this slot applies the AED unitary
     const int tau0 = st.tau[ch][par];
     bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
     const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
     int w0 = 0, w1 = 0, tau_end = 0;
     if (move) {
         chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
-        if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several launches
+        if (tau_end > tau0 + wmax - 1) tau_end = tau0 + wmax - 1;      // first and last window of a sweep: several launches
         if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
             // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
             // this step); this chain may only work strictly above it
@@ -614,6 +620,9 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (t == 0) {
             if (st.w0[ch] != 0 || st.w1[ch] != 0) { st_all[b].w0[ch] = 0; st_all[b].w1[ch] = 0; }
             st_all[b].tau[ch][par ^ 1] = tau0;
+            // nothing new to apply in this step.  (With the look-ahead schedule the update kernels of a step read the parity copy: an
+            // idle, finished or small-block-applied matrix must not see the window its previous step of this parity left there.)
+            if (look) publish(0, 0, 0, 0);
         }
         return;
     }
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
     }
     if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
-    cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    cx<T>* U = Uall + ((long)b * QKC + (look ? 1 + par : ch)) * QW * QW;      // look-ahead (one chain): chain slots 1, 2 double-buffer the step's unitary
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
     {
         // phase 1 done: the window goes back to H, the buffer becomes U = I
@@ -751,7 +760,19 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             }
         }
     }
-    if (t == 0) { st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1; }
+    if (t == 0) {
+        st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1;
+        if (look) {
+            // columns right of this window that the next window covers: their left update is the critical part of this step
+            int gc = 0;
+            if (tau_end + 1 <= st.tau_last[ch]) {
+                int n0, n1, ne;
+                chain_window(ilo, ihi, k, tau_end + 1, st.tau_last[ch], n0, n1, ne);
+                if (n1 > w1) gc = (n1 - w1 + 15) >> 4;
+            }
+            publish(w0, w1, gc, 1 + par);
+        }
+    }
     if (dbg) dbg[14] += clock64() - tk0;
 }
 
@@ -876,7 +897,14 @@ __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, con
 // 3M variant of one K half for the tile pair (2 pp, 2 pp + 1): three real MFMAs per k-step and tile (mfma.hpp).
 //   right update (C = X U):    P1 += xr ur,  P2 += xi ui,  P3 += (xr + xi)(ur + ui);   Cr = P1 - P2,  Ci = P3 - P1 - P2
 //   left update  (C = U^H X):  P1 += ur xr,  P2 += ui xi,  P3 += (ur - ui)(xr + xi);   Cr = P1 + P2,  Ci = P3 - P1 + P2
-template <class T, int SIDE>
+//
+// BAND: the unitary of a chain step is a product of at most QNS bulge passes, each an ascending sequence of adjacent-column
+// rotations, i.e. an upper Hessenberg matrix (rotations of different bulges that are interleaved in time act two or more columns apart
+// and commute into that order): U has at most QNS = 16 nonzero subdiagonals.  With 16-wide k chunks c and 16-wide output tiles t
+// (t indexes the COLUMNS of U on either side) the block (c, t) is structurally zero for c >= t + 2 -- (2,0), (3,0), (3,1): 3 of the
+// 16 blocks, 19 % of the matrix-core work.  The conditions fold at compile time (h, pp, cc, q are unrolled constants); whether a
+// given U has the band is decided by the kernel when it stages U into LDS (dense AED / small-block unitaries use the same kernel).
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int pp, int lane, const cx<T> (&x)[8],
                                                       typename Mfma<T>::acc_t (&p1)[2], typename Mfma<T>::acc_t (&p2)[2], typename Mfma<T>::acc_t (&p3)[2]) {
     const int lr = lane & 15, lk = lane >> 4;
@@ -884,29 +912,33 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int chunk = 2 * h + cc;
+            const bool use0 = !(BAND && chunk >= 2 * pp + 2), use1 = !(BAND && chunk >= 2 * pp + 3);       // tiles 2pp, 2pp + 1
+            if (!use0 && !use1) continue;
             const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 32 * pp;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
             const T xs = xr + xi;
             T ur[2], ui[2], us[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if (!(q == 0 ? use0 : use1)) continue;
                 ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
                 us[q] = SIDE == 1 ? ur[q] + ui[q] : ur[q] - ui[q];
             }
             if (SIDE == 1) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(xr, ur[q], p1[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p1[q] = Mfma<T>::mma(xr, ur[q], p1[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(xi, ui[q], p2[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p2[q] = Mfma<T>::mma(xi, ui[q], p2[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(xs, us[q], p3[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p3[q] = Mfma<T>::mma(xs, us[q], p3[q]);
             } else {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p1[q] = Mfma<T>::mma(ur[q], xr, p1[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p1[q] = Mfma<T>::mma(ur[q], xr, p1[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p2[q] = Mfma<T>::mma(ui[q], xi, p2[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p2[q] = Mfma<T>::mma(ui[q], xi, p2[q]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) p3[q] = Mfma<T>::mma(us[q], xs, p3[q]);
             }
             // bound the hoisting of the U fragment reads to the next two k-steps: unbounded, hipcc keeps the fragments of a whole K half
             // live (96 registers), which the register double buffer of the streamed operand has no room for
@@ -970,21 +1002,21 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
     }
 }
 
-template <class T, int SIDE, bool FULL = false>
+template <class T, int SIDE, bool FULL = false, bool BAND = false>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]);
 
-template <class T, int SIDE>
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane) {
     cx<T> xa[8], xb[8];
     slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
     slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
-    slab_compute<T, SIDE>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+    slab_compute<T, SIDE, false, BAND>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
 }
 
 // multiply + store of one strip whose streamed operand is already in (or on its way to) registers
-template <class T, int SIDE, bool FULL>
+template <class T, int SIDE, bool FULL, bool BAND>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
     if constexpr (sizeof(T) == 8) {
@@ -998,8 +1030,8 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { p1[q][r] = T(0); p2[q][r] = T(0); p3[q][r] = T(0); }
-            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 0, pp, lane, xa, p1, p2, p3);
-            slab_multiply_half_3m<T, SIDE>(Ur, Ui, 1, pp, lane, xb, p1, p2, p3);
+            slab_multiply_half_3m<T, SIDE, BAND>(Ur, Ui, 0, pp, lane, xa, p1, p2, p3);
+            slab_multiply_half_3m<T, SIDE, BAND>(Ur, Ui, 1, pp, lane, xb, p1, p2, p3);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1060,7 +1092,7 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                            QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work, int nslab, int dynamic) {
+                                                           unsigned* __restrict__ work, int nslab, int dynamic, int band_on) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1079,13 +1111,18 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
         atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
     const cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    int dense = 0;                            // any nonzero in the blocks the banded product skips?
     for (int e = t; e < QW * QW; e += 256) {
         const int k = e >> 6, c = e & 63;
         cx<T> u(T(0), T(0));
         if (k < ww && c < ww) u = U[k * QW + c];
         Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
     }
+    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);          // [4] per-wave votes, behind the planes
+    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
     __syncthreads();
+    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
     cx<T>* H = Aall + (long)b * mstride;
     cx<T>* Z = Zall + (long)b * mstride;
     if (PART == 2 && dynamic) {
@@ -1099,8 +1136,13 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         for (int g = claim(); g < S;) {
             const int gn = claim();
             const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
-            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            if (band) {
+                if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+                else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+            } else {
+                if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+                else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            }
             g = gn;
         }
         return;
@@ -1109,8 +1151,82 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         const int g = g0 + wave + 4 * i;
         if (g >= S) break;
         const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
-        if (PART == 0 || (PART == 2 && d.side == 0)) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-        else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        const bool left = PART == 0 || (PART == 2 && d.side == 0);
+        if (band) {
+            if (left) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+        } else {
+            if (left) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        }
+    }
+}
+
+// Off-window update of one step of the LOOK-AHEAD schedule (knob qr_look; one chain per sweep).  The update of step k is cut in two:
+//   phase 0 ("critical")  the first lgc left strips = the columns right of window k that window k+1 covers.  It runs on the group's
+//                         main stream between the two chases (after the remaining update of step k-1, whose rows it shares).
+//   phase 1 ("remaining") all other left strips, the right strips of H and the strips of Z, on the group's SECOND stream, while
+//                         window k+1 is chased: it touches nothing of window k+1 (rows >= w0(k+1) only in columns >= w1(k+1)).
+// Ordering (host side, events): chase k -> critical k -> chase k+1;  remaining k after critical k and remaining k-1;  critical k+1
+// after remaining k.  Everything a step's kernels read (window, U slot, strip counter) sits under the step's parity in QrState, the
+// chase of the next step writes the other parity.  Strips of the remaining update are claimed dynamically.
+template <class T>
+__global__ __launch_bounds__(256, 2) void apply_look_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+                                                         QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
+                                                         unsigned* __restrict__ work, int par, int phase, int band_on) {
+    TRX_DYN_SMEM(smem);
+    T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
+    T* Ui = Ur + QW * MLD;
+    const int b = blockIdx.y;
+    const int w0 = st_all[b].lw0[par], w1 = st_all[b].lw1[par];
+    const int ww = w1 - w0;
+    if (ww <= 0) return;
+    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
+    int gc = st_all[b].lgc[par];
+    if (gc > nL) gc = nL;
+    const int S = phase == 0 ? gc : nL - gc + nR + nZ;
+    if (phase == 0 ? (int)blockIdx.x * 4 >= S : *(volatile int*)&st_all[b].lstrip[par] >= S) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (phase == 1 && blockIdx.x == 0 && t == 0) atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
+    const cx<T>* U = Uall + ((long)b * QKC + st_all[b].lus[par]) * QW * QW;
+    int dense = 0;
+    for (int e = t; e < QW * QW; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        cx<T> u(T(0), T(0));
+        if (k < ww && c < ww) u = U[k * QW + c];
+        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
+    }
+    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);
+    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
+    __syncthreads();
+    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
+    cx<T>* H = Aall + (long)b * mstride;
+    cx<T>* Z = Zall + (long)b * mstride;
+    auto run = [&](int g) {              // strip g of the step's full list: left | right-H | Z
+        const SlabStrip<T> d = slab_locate<T, 2>(g, nL, nR, H, Z, n, w0, w1);
+        if (band) {
+            if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+        } else {
+            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+        }
+    };
+    if (phase == 0) {
+        for (int g = blockIdx.x * 4 + wave; g < S; g += 4 * gridDim.x) run(g);
+        return;
+    }
+    auto claim = [&]() {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&st_all[b].lstrip[par], 1);
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    for (int g = claim(); g < S;) {
+        const int gn = claim();
+        run(g + gc);
+        g = gn;
     }
 }
 
@@ -1263,7 +1379,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, look = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1285,6 +1401,8 @@ static QrKnobs& qr_knobs() {
         q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
+        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);
+        q.look = geti("TRX_QR_LOOK", 0, 3, 0);                // 2: look-ahead schedule (off-window update of step k under the chase of step k+1)              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1300,7 +1418,16 @@ struct QrLane {
     int* hsum = nullptr;               // pinned host memory, 2 x 4 ints
     int dev = -1;
     bool has_stream = false;
+    hipStream_t s2 = nullptr;          // look-ahead schedule: the stream of the remaining updates (created on first use)
+    hipEvent_t evA[2] = {nullptr, nullptr}, evR[2] = {nullptr, nullptr};   // "critical update of step k done" / "remaining update of step k done", k % 2
 };
+static bool lane_look_ready(QrLane& l) {
+    if (l.s2) return true;
+    if (hipStreamCreateWithFlags(&l.s2, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&l.evA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.evR[i], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
@@ -1338,6 +1465,8 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_dyn") { slot = &k.dyn; hi = 2; }
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
+    else if (s == "slab_band") { slot = &k.band; hi = 2; }
+    else if (s == "qr_look") { slot = &k.look; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1350,7 +1479,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
     const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
-    const size_t sma = sizeof(T) * 2 * QW * MLD;
+    const size_t sma = sizeof(T) * 2 * QW * MLD + 16;        // + the four per-wave band votes
     auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
     static std::once_flag attr_once[2];
     int attr_rc = 0;
@@ -1359,7 +1488,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) || set_max_dyn_smem((const void*)apply_look_kernel<T>, sma) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp_of(SM));
     });
     if (attr_rc) return TRX_ERR_LAUNCH;
@@ -1384,6 +1513,14 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // overlaps the loads of one wave with the MFMAs of its SIMD neighbour, and the static strips the pipeline needs bring back
     // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
     const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
+    const int band_on = K.band != 1;
+    // look-ahead schedule (one chain per sweep): see apply_look_kernel.  Opt-in (knob qr_look = 2) until it is measured.
+    const bool look = K.look >= 2 && kc == 1;
+    // A chase workgroup of the look-ahead schedule has to find room on a CU that also holds ONE slab-update workgroup (74 KB of
+    // the 160 KB): with a rotation log of 48 instead of 96 chain steps it needs 85 KB instead of 104 KB.  The first window of a
+    // sweep (62 steps) and a clipped last one then take two launches.
+    const int wmax_look = 48;
+    const size_t smw_look = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * wmax_look * QNS + sizeof(QrState);
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1401,6 +1538,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
+        bool have_r;           // look-ahead: a remaining update has been queued on the second stream
     };
     // 4 groups = the number of hardware queues a HIP process gets by default; beyond that streams share queues and serialise
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
@@ -1424,7 +1562,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.work = 0;
         G.par = 0;
         G.g = g;
+        G.have_r = false;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
+        if (look && !lane_look_ready(G.lane)) { rc = TRX_ERR_LAUNCH; ++nlanes; break; }
         ++nlanes;
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
@@ -1464,12 +1604,52 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary); every further chain
         // enters about 3 steps behind the one ahead.  `bound` is one iteration old, i.e. already a step or so generous, and a sweep
         // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
-        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
+        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) + (look ? 2 : 0) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
+        if (look) {
+            // chase k -> critical k -> chase k+1 on the group's stream; remaining k on the second stream (after critical k, before
+            // critical k+1); the prepare kernel that follows the sweep waits for the last remaining update
+            int wgm = (K.wgs ? K.wgs : 448) / G.nb;          // < 2 per CU over the group: the chase of the next step needs CUs of its own
+            wgm = wgm < 1 ? 1 : (wgm > 32 ? 32 : wgm);
+            if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
+            hipStream_t s2 = G.lane.s2;
+            auto remaining = [&](int par) {
+                (void)hipStreamWaitEvent(s2, G.lane.evA[par], 0);
+                { ProfScope p(PROF_QR_APPLY_RIGHT, s2, 0, 0);
+                  TRX_LAUNCH((apply_look_kernel<T>), dim3(wgm, G.nb), dim3(256), sma, s2, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 1, band_on); }
+                (void)hipEventRecord(G.lane.evR[par], s2);
+                G.have_r = true;
+            };
+            // qr_look = 3 (tests): the remaining update of step k is ISSUED after the chase of step k+1 instead of before it -- an
+            // order the events allow just as well.  On the in-order CPU emulator the two issue orders are the two extreme
+            // interleavings of "remaining k" with "chase k+1", so equal results there check that the two really are independent.
+            const bool defer = K.look == 3;
+            int pending = -1;
+            for (int q = 0; q < nwin; ++q) {
+                const int par = G.par;
+                { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
+                  TRX_LAUNCH((qr_window_kernel<T, false>), dim3(1, G.nb), dim3(WTHREADS), smw_look, G.s, Ag, mstride, n, stg, Ug, shg, par, (long long*)nullptr, 1, wmax_look); }
+                if (pending >= 0) { remaining(pending); pending = -1; }
+                if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[par ^ 1], 0);
+                TRX_LAUNCH((apply_look_kernel<T>), dim3(1, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 0, band_on);
+                (void)hipEventRecord(G.lane.evA[par], G.s);
+                if (q == 0) {
+                    // the first slot of a sweep applies the unitary of the prepare kernel (AED window / finished small block) where
+                    // there is one: its rows and columns are not related to the first chase window, so nothing of it may overlap
+                    remaining(par);
+                    (void)hipStreamWaitEvent(G.s, G.lane.evR[par], 0);
+                } else if (defer) pending = par;
+                else remaining(par);
+                G.par ^= 1;
+            }
+            if (pending >= 0) remaining(pending);
+            if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[G.par ^ 1], 0);
+            return;
+        }
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev, 0, WMAXS);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr, 0, WMAXS); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
@@ -1486,18 +1666,18 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               if (kc == 1 && dyn && pipe) {
                   if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk);
               } else if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn);
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
               } }
         }
     };

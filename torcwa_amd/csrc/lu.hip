@@ -10,6 +10,7 @@
 //   gemm                 A22 -= L21 U12
 #include "common.hpp"
 #include "prof.hpp"
+#include <string>
 
 namespace trx {
 namespace {
@@ -94,6 +95,205 @@ __global__ __launch_bounds__(512) void lu_panel_kernel(cx<T>* __restrict__ Aall,
                     cx<T>* p = A + (long)i * lda + k0 + cpart;
                     *p = (*p) * ri;
                 }
+        }
+    }
+}
+
+// ---- row-split panel for a FEW LARGE matrices ---------------------------------------------------------------------------------
+// One workgroup per matrix streams the whole (n-k0) x jb panel through one CU jb times: 1.35 ms per panel at n = 5202, a quarter of
+// the forward + adjoint step of a single [25,25] solve.  With few matrices the panel is instead cut into row blocks, W workgroups
+// per matrix, ONE launch per panel column, and the pivoting is IMPLICIT inside the panel (no row is moved until the panel is done),
+// which is what makes a launch free of cross-workgroup hazards:
+//   lu_split_cand_kernel    candidates of column 0: each row block's largest |a| (LAPACK's |re|+|im|) -> cand[0][w] = row
+//   lu_split_col_kernel(j)  every workgroup reduces the W candidates of column j to the pivot row p (the same result everywhere; block
+//                           0 records it in piv[k0+j]), reads row p -- which nobody writes in this launch: a pivot row is frozen
+//                           from the moment it is chosen -- and eliminates column j from its own rows that are not pivots yet
+//                           (rank-1 update of columns j+1..jb-1), collecting on the way its candidate
+//                           for column j+1 -> cand[(j+1)&1][w].  The rows chosen so far are the <= jb entries piv[k0..k0+j).
+//   lu_split_scale_kernel   scales the multipliers (kept unscaled while the columns are eliminated, like in the one-workgroup kernel)
+//   lu_split_final_kernel   turns the list of chosen rows into LAPACK's sequential interchanges (piv[k0+j] = position swapped with
+//                           position k0+j) and applies them to the panel columns; lu_swap_kernel then does the other columns as
+//                           usual.  Row k0+j ends up as [multipliers of columns < j | U row j]: the standard layout.
+// The pivot of each column is the same largest-magnitude element as in the one-workgroup kernel (exact ties may resolve to another
+// row: the candidates are ordered by their original row index, not by their current position).
+// The candidate lists live in the not-yet-written tail of the pivot array (piv[k0+jb ...), 2 W ints), so the C ABI is unchanged;
+// the split path is used while that tail is long enough and the panel tall enough (rows >= lu_split rows, default 1024).
+constexpr int LSW_MAX = 64;             // workgroups per matrix
+constexpr int LST = 256;                // threads per workgroup
+
+template <class T>
+__device__ __forceinline__ void lu_split_rows(int n, int k0, int W, int w, int& r0, int& r1) {
+    const int rows = n - k0, per = (rows + W - 1) / W;
+    r0 = k0 + w * per;
+    r1 = r0 + per < n ? r0 + per : n;
+    if (r0 > n) r0 = n;
+}
+
+// block reduction of (value, row): larger value wins, ties -> smaller row; result valid in thread 0
+template <class T>
+__device__ __forceinline__ void lu_best_reduce(T& best, int& bi, T* red_v, int* red_i) {
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { red_v[wid] = best; red_i[wid] = bi; }
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 1; q < LST / 64; ++q)
+            if (red_v[q] > best || (red_v[q] == best && red_i[q] < bi)) { best = red_v[q]; bi = red_i[q]; }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(LST) void lu_split_cand_kernel(const cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int W,
+                                                             int* __restrict__ piv_all) {
+    __shared__ T red_v[LST / 64];
+    __shared__ int red_i[LST / 64];
+    const int b = blockIdx.y, w = blockIdx.x;
+    const cx<T>* A = Aall + (long)b * sA;
+    int* cand = piv_all + (long)b * n + k0 + jb;          // [2][W]
+    int r0, r1;
+    lu_split_rows<T>(n, k0, W, w, r0, r1);
+    T best = T(-1);
+    int bi = n;
+    for (int r = r0 + threadIdx.x; r < r1; r += LST) {
+        const T v = abs1(A[(long)r * lda + k0]);
+        if (v > best) { best = v; bi = r; }
+    }
+    lu_best_reduce<T>(best, bi, red_v, red_i);
+    if (threadIdx.x == 0) cand[w] = bi;                   // n = "no row" (empty block)
+}
+
+template <class T>
+__global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int j, int W,
+                                                            int* __restrict__ piv_all, int* __restrict__ info_all) {
+    __shared__ cx<T> prow[NB];
+    __shared__ int chosen[NB];
+    __shared__ T red_v[LST / 64];
+    __shared__ int red_i[LST / 64];
+    __shared__ int s_p;
+    const int b = blockIdx.y, w = blockIdx.x, t = threadIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    int* piv = piv_all + (long)b * n;
+    const int* cand = piv + k0 + jb + (j & 1) * W;
+    int* cand_next = piv + k0 + jb + ((j + 1) & 1) * W;
+    const int col = k0 + j;
+    // pivot of column j: the largest of the W candidates (every workgroup computes the same)
+    {
+        T best = T(-1);
+        int bi = n;
+        if (t < W) {
+            const int r = cand[t];
+            if (r < n) { best = abs1(A[(long)r * lda + col]); bi = r; }
+        }
+        lu_best_reduce<T>(best, bi, red_v, red_i);
+        if (t == 0) {
+            s_p = bi;
+            if (w == 0) {
+                piv[col] = bi;                            // chosen ROW (turned into an interchange by lu_split_final_kernel)
+                if (!(best > T(0)) && info_all[b] == 0) info_all[b] = col + 1;
+            }
+        }
+        __syncthreads();
+    }
+    const int p = s_p;
+    if (t < j) chosen[t] = piv[k0 + t];
+    if (t == j) chosen[j] = p;
+    if (t < jb && p < n) prow[t] = A[(long)p * lda + k0 + t];
+    __syncthreads();
+    if (p >= n) { if (t == 0) cand_next[w] = n; return; }           // no row left (cannot happen while col < n)
+    const cx<T> pv = prow[j];
+    const cx<T> ri = (pv.x != T(0) || pv.y != T(0)) ? crecip(pv) : cx<T>(T(0), T(0));
+    int r0, r1;
+    lu_split_rows<T>(n, k0, W, w, r0, r1);
+    // 16 lanes per row (2 columns each), 16 rows in flight
+    const int cpart = t & 15, rpart = t >> 4;
+    T best = T(-1);
+    int bi = n;
+    for (int r = r0 + rpart; r < r1; r += LST / 16) {
+        bool done = false;
+        for (int q = 0; q <= j; ++q) done |= (chosen[q] == r);
+        if (done) continue;
+        cx<T>* row = A + (long)r * lda + k0;
+        const cx<T> l = row[j] * ri;             // the multiplier itself stays unscaled in memory until lu_split_scale_kernel
+        for (int c = j + 1 + cpart; c < jb; c += 16) {
+            const cx<T> v = row[c] - l * prow[c];
+            row[c] = v;
+            if (c == j + 1) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
+        }
+    }
+    if (j + 1 < jb) {
+        lu_best_reduce<T>(best, bi, red_v, red_i);
+        if (t == 0) cand_next[w] = bi;
+    }
+}
+
+// L[r, j] = a[r, j] / u_jj for every column j at which row r was not a pivot yet (rows still at their original positions)
+template <class T>
+__global__ __launch_bounds__(LST) void lu_split_scale_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int W,
+                                                              const int* __restrict__ piv_all) {
+    __shared__ cx<T> rinv[NB];
+    __shared__ int chosen[NB];
+    const int b = blockIdx.y, w = blockIdx.x, t = threadIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    const int* piv = piv_all + (long)b * n;
+    if (t < jb) {
+        const int p = piv[k0 + t];
+        chosen[t] = p;
+        cx<T> d(T(0), T(0));
+        if (p < n) d = A[(long)p * lda + k0 + t];          // u_tt: the owner of row p scales only its columns < t
+        rinv[t] = (d.x != T(0) || d.y != T(0)) ? crecip(d) : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    int r0, r1;
+    lu_split_rows<T>(n, k0, W, w, r0, r1);
+    const int cpart = t & 31, rpart = t >> 5;
+    for (int r = r0 + rpart; r < r1; r += LST / 32) {
+        int cend = jb;
+        for (int q = 0; q < jb; ++q) if (chosen[q] == r) cend = q;
+        if (cpart < cend) {
+            cx<T>* e = A + (long)r * lda + k0 + cpart;
+            *e = (*e) * rinv[cpart];
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void lu_split_final_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int* __restrict__ piv_all) {
+    __shared__ int key[2 * NB], pos[2 * NB];             // original row -> current position, for the rows that have moved
+    __shared__ int seq[NB];
+    const int b = blockIdx.x, t = threadIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    int* piv = piv_all + (long)b * n;
+    if (t == 0) {
+        int nk = 0;
+        auto where = [&](int orig) { for (int q = 0; q < nk; ++q) if (key[q] == orig) return pos[q]; return orig; };
+        auto put = [&](int orig, int at) { for (int q = 0; q < nk; ++q) if (key[q] == orig) { pos[q] = at; return; } key[nk] = orig; pos[nk] = at; ++nk; };
+        for (int j = 0; j < jb; ++j) {
+            const int target = piv[k0 + j];               // original row chosen for column j
+            const int here = k0 + j;
+            const int q = where(target);                  // where it sits now
+            // the row now at position `here` is the original row `o` with where(o) == here
+            int o = here;
+            for (int z = 0; z < nk; ++z) if (pos[z] == here) o = key[z];
+            seq[j] = q;
+            if (q != here) { put(target, here); put(o, q); }
+        }
+        for (int j = 0; j < jb; ++j) piv[k0 + j] = seq[j];
+    }
+    __syncthreads();
+    if (t < jb) {
+        const int c = k0 + t;
+        for (int j = 0; j < jb; ++j) {
+            const int r = k0 + j, p = seq[j];
+            if (p != r) {
+                const cx<T> a = A[(long)r * lda + c];
+                A[(long)r * lda + c] = A[(long)p * lda + c];
+                A[(long)p * lda + c] = a;
+            }
         }
     }
 }
@@ -193,6 +393,17 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
+static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
+static int g_lu_split_batch = 0;          // 0 = automatic (2): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
+int lu_set_knob(const char* key, int value) {
+    const std::string k(key);
+    if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
+    if (k == "lu_split") g_lu_split_rows = value;
+    else if (k == "lu_split_batch") g_lu_split_batch = value;
+    else return TRX_ERR_ARG;
+    return TRX_OK;
+}
+
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
     if (n <= 0 || batch <= 0) return TRX_OK;
@@ -205,8 +416,26 @@ int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int ba
         const int Kend = K0 + kb;
         for (int c0 = K0; c0 < Kend; c0 += NB) {
             const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-            { ProfScope prof(PROF_LU_PANEL, s, 0, 0);
-              TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info); }
+            // few large matrices: row-split panel (see above); needs 2 W ints of the pivot array's unwritten tail
+            const int rows = n - c0;
+            const int split_min = g_lu_split_rows ? g_lu_split_rows : 1024;
+            // workgroups per matrix: about 512 per launch over the batch, at least 64 rows each (a larger batch already supplies
+            // workgroups, but the one-workgroup panel still leaves half of the CUs idle at batch 128: knob lu_split_batch)
+            const int split_batch = g_lu_split_batch ? g_lu_split_batch : 2;
+            int W = rows / 64 < LSW_MAX ? rows / 64 : LSW_MAX;
+            const int wcap = 512 / batch > 2 ? 512 / batch : 2;
+            if (W > wcap) W = wcap;
+            if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
+                ProfScope prof(PROF_LU_PANEL, s, 0, 0);
+                TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
+                for (int j = 0; j < jb; ++j)
+                    TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info);
+                TRX_LAUNCH((lu_split_scale_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, W, (const int*)piv);
+                TRX_LAUNCH((lu_split_final_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, piv);
+            } else {
+                ProfScope prof(PROF_LU_PANEL, s, 0, 0);
+                TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
+            }
             if (n - jb > 0)
                 TRX_LAUNCH((lu_swap_kernel<T>), dim3(cdiv_i(n - jb, 256), batch), dim3(256), 0, s, A, lda, sA, n, c0, jb, (const int*)piv, n);
             const int wcols = Kend - (c0 + jb);       // columns of the outer block still to be factored
