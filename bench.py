@@ -263,7 +263,7 @@ def roofline(engine, args, elapsed, steps, n, units_per_step):
     import ctypes
     peak_tf = PEAK_TFLOPS[args.precision]
     kernels = []
-    for tag in range(8):
+    for tag in range(9):
         buf = (ctypes.c_double * 6)()
         engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
         launches, timed, flops_t, bytes_t, ms, flops_all = list(buf)

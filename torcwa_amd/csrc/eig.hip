@@ -4,6 +4,8 @@
 // Hessenberg reduction (eig_hess.hip) -> multi-shift QR to Schur form (eig_qr.hip) -> triangular eigenvectors + back-transform
 // + undo of the balancing + unit-norm scaling (eig_vec.hip).
 #include "eig.hpp"
+#include <cstdlib>
+#include <string>
 
 namespace trx {
 
@@ -13,7 +15,8 @@ template <class T>
 size_t eig_ws_bytes_t(int n, int batch) {
     const size_t e = sizeof(cx<T>), B = batch, N = n;
     size_t tot = 0;
-    tot += al256(e * B * N * N) * 2;                                  // Z, X
+    tot += al256(e * B * N * N) * 3;                                  // Z, X, Ht
+    tot += al256(B * N * N) + al256(sizeof(T) * B);                   // SW, hnorm
     tot += al256(e * B * N * EigPlan::HNB) * 2;                       // Vp, Yp
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Tp
     tot += al256(e * B * EigPlan::HNB * N) * 2;                       // W1, W2
@@ -36,6 +39,9 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.A = (cx<T>*)A;
     Bf.Z = (cx<T>*)take(e * B * N * N);
     Bf.X = (cx<T>*)take(e * B * N * N);
+    Bf.Ht = (cx<T>*)take(e * B * N * N);
+    Bf.SW = (unsigned char*)take(B * N * N);
+    Bf.hnorm = (T*)take(sizeof(T) * B);
     Bf.Vp = (cx<T>*)take(e * B * N * EigPlan::HNB);
     Bf.Yp = (cx<T>*)take(e * B * N * EigPlan::HNB);
     Bf.Tp = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
@@ -52,6 +58,18 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
     Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
+}
+
+static int eig_vec_env() {
+    const char* e = getenv("TRX_EIG_VEC");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 0 && v <= 2) ? v : 0;
+}
+static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (inverse iteration), 1 Schur vectors, 2 inverse iteration
+int eig_set_knob(const char* key, int value) {
+    if (std::string(key) != "eig_vec" || value < 0 || value > 2) return TRX_ERR_ARG;
+    g_eig_vec = value;
+    return TRX_OK;
 }
 
 namespace {
@@ -73,8 +91,16 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     rc = hessenberg<T>(s, B, n, batch);
     if (rc) return rc;
     TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
-    rc = hessenberg_qr<T>(s, B, n, batch, info);
+    // Eigenvector route (knob eig_vec: 0 = automatic, 1 = Schur vectors, 2 = inverse iteration).  Inverse iteration (eig_invit.hip): the
+    // QR phase runs for eigenvalues only -- a third of the off-window work and no Z -- and each eigenvector costs one O(n^2) solve.
+    const bool invit = g_eig_vec != 1 && n <= INVIT_NMAX && n >= 2;
+    if (invit) {
+        rc = invit_prepare<T>(s, B, n, batch);
+        if (rc) return rc;
+    }
+    rc = hessenberg_qr<T>(s, B, n, batch, info, invit ? 0 : 1);
     if (rc) return rc;
+    if (invit) return invit_vectors<T>(s, B, n, batch, (cx<T>*)w, (cx<T>*)V);
     return schur_vectors<T>(s, B, n, batch, (cx<T>*)w, (cx<T>*)V);
 }
 }  // namespace
@@ -158,8 +184,9 @@ extern "C" int trx_eig_backward(int dtype, const void* w, const void* V, const v
 
 extern "C" int trx_tuning(const char* key, int value) {
     if (!key) return TRX_ERR_ARG;
-    const int rc = trx::qr_set_knob(key, value);
-    return rc == TRX_OK ? rc : trx::lu_set_knob(key, value);
+    int rc = trx::qr_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::lu_set_knob(key, value);
+    return rc == TRX_OK ? rc : trx::eig_set_knob(key, value);
 }
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {

@@ -27,12 +27,6 @@ struct QrState {
     int w0[EigPlan::QKC], w1[EigPlan::QKC];   // window of each chain's last step: its pending off-window update acts on [w0, w1)
     int fail;                     // number of unconverged eigenvalues on failure
     int strip_next;               // next unclaimed strip of the pending off-window update (dynamic strip scheduling; reset per window step)
-    // look-ahead schedule (knob qr_look, one chain): the off-window update of window step k runs on a second stream while step k+1
-    // is chased, so what it reads is double-buffered by the parity of the step
-    int lw0[2], lw1[2];           // window of the step
-    int lgc[2];                   // left strips (16 columns) right of the window that the NEXT window needs: updated first ("critical")
-    int lus[2];                   // slot of U that holds the step's unitary (0: written by the prepare kernel, 1 + parity: by the chase)
-    int lstrip[2];                // dynamic strip counter of the step's remaining update
 };
 enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
 
@@ -40,7 +34,10 @@ template <class T>
 struct EigBuffers {
     cx<T>* A;      // [B,n,n] input, becomes H then T
     cx<T>* Z;      // [B,n,n] accumulated unitary
-    cx<T>* X;      // [B,n,n] triangular eigenvectors
+    cx<T>* X;      // [B,n,n] triangular eigenvectors (Schur route) / eigenvectors of H (inverse iteration)
+    cx<T>* Ht;     // [B,n,n] transposed copy of the Hessenberg matrix (inverse iteration streams its columns)
+    unsigned char* SW;   // [B,n,n] interchange flags of the inverse-iteration eliminations
+    T* hnorm;      // [B] infinity norm of the Hessenberg matrix
     cx<T>* Vp;     // [B,n,HNB] panel reflectors (dense, explicit zeros/ones)
     cx<T>* Yp;     // [B,n,HNB]
     cx<T>* Tp;     // [B,HNB,HNB]
@@ -64,8 +61,16 @@ template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, in
 
 template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
-template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
+// wantz = 1: Schur form (T in A, unitary accumulated into Z);  wantz = 0: eigenvalues only (diagonal of A on return; the off-window
+// updates are restricted to the active diagonal block, A is NOT a Schur form afterwards and Z is not touched)
+template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info, int wantz);
 int qr_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
+// V <- D V (undo of the balancing) with unit 2-norm columns
+template <class T> int finish_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* V);
+// eigenvectors by inverse iteration on the Hessenberg matrix (eig_invit.hip): invit_prepare before the QR phase, invit_vectors after it
+template <class T> int invit_prepare(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
+template <class T> int invit_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
+constexpr int INVIT_NMAX = 8192;      // largest n the inverse-iteration kernel is laid out for
 
 }  // namespace trx

@@ -317,7 +317,7 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        int sm, long long* dbg_all = nullptr) {
+                                                        int sm, int wantz, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
@@ -407,7 +407,8 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         }
         if (lane == 0) {
             clear_windows(st);
-            st.w0[0] = ilo; st.w1[0] = ihi + 1; st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
+            if (wantz) { st.w0[0] = ilo; st.w1[0] = ihi + 1; }        // eigenvalues only: nothing outside the finished block needs its unitary
+            st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
             if (!ok) st.fail += m;
             stall_[b] = st;
             atomicAdd(&summary[0], 1);
@@ -579,35 +580,29 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr, int look = 0, int wmax = WMAXS) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
     RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
-    QrState& sst = *reinterpret_cast<QrState*>(rlog + wmax * QNS);        // wmax <= WMAXS: chain steps per launch (sizes the log)
+    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
     __syncthreads();
     const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
     // positions go to the [par] copy, which nobody writes in this step.
-    // look-ahead schedule: publish what the update kernels of THIS step read, under the step's parity (they run while the next step,
-    // of the other parity, is chased).  A slot that applies a unitary of the prepare kernel has no next window: nothing is critical.
-    auto publish = [&](int pw0, int pw1, int gc, int slot) {
-        QrState& g = st_all[b];
-        g.lw0[par] = pw0; g.lw1[par] = pw1; g.lgc[par] = gc; g.lus[par] = slot; g.lstrip[par] = 0;
-    };
-    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) { st_all[b].mode = QR_SMALL_APPLIED; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }      // this slot applies the block's unitary
-    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) { st_all[b].mode = QR_CHASE; if (look) publish(st.w0[0], st.w1[0], 0, 0); } return; }                  // this slot applies the AED unitary
+    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
+    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) st_all[b].mode = QR_CHASE; return; }                  // this slot applies the AED unitary
     const int tau0 = st.tau[ch][par];
     bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
     const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
     int w0 = 0, w1 = 0, tau_end = 0;
     if (move) {
         chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
-        if (tau_end > tau0 + wmax - 1) tau_end = tau0 + wmax - 1;      // first and last window of a sweep: several launches
+        if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several launches
         if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
             // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
             // this step); this chain may only work strictly above it
@@ -620,9 +615,6 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (t == 0) {
             if (st.w0[ch] != 0 || st.w1[ch] != 0) { st_all[b].w0[ch] = 0; st_all[b].w1[ch] = 0; }
             st_all[b].tau[ch][par ^ 1] = tau0;
-            // nothing new to apply in this step.  (With the look-ahead schedule the update kernels of a step read the parity copy: an
-            // idle, finished or small-block-applied matrix must not see the window its previous step of this parity left there.)
-            if (look) publish(0, 0, 0, 0);
         }
         return;
     }
@@ -709,7 +701,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
     }
     if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
-    cx<T>* U = Uall + ((long)b * QKC + (look ? 1 + par : ch)) * QW * QW;      // look-ahead (one chain): chain slots 1, 2 double-buffer the step's unitary
+    cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
     {
         // phase 1 done: the window goes back to H, the buffer becomes U = I
@@ -762,16 +754,6 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     }
     if (t == 0) {
         st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1;
-        if (look) {
-            // columns right of this window that the next window covers: their left update is the critical part of this step
-            int gc = 0;
-            if (tau_end + 1 <= st.tau_last[ch]) {
-                int n0, n1, ne;
-                chain_window(ilo, ihi, k, tau_end + 1, st.tau_last[ch], n0, n1, ne);
-                if (n1 > w1) gc = (n1 - w1 + 15) >> 4;
-            }
-            publish(w0, w1, gc, 1 + par);
-        }
     }
     if (dbg) dbg[14] += clock64() - tk0;
 }
@@ -802,15 +784,33 @@ struct SlabStrip {       // wave-uniform description of one strip
     int a0, lim;         // first column / row of the strip, end of the valid column / row range
 };
 
+// Regions of the off-window update of one window step.  wantz (Schur form): left update on all columns right of the window, right update
+// on all rows above it, and the window's columns of Z.  Eigenvalues only: the left update stops at the end of the active block, the right
+// update starts at its first row, Z is not touched -- everything outside the active diagonal block is irrelevant to the eigenvalues.
+struct SlabRanges {
+    int nL, nR, nZ;      // strips (16 columns / rows) of the left update, the right update of H, the update of Z
+    int lc0, lclim;      // left update: first column, end of the column range
+    int rr0;             // right update of H: first row (the range ends at w0)
+};
+__device__ __forceinline__ SlabRanges slab_ranges(const QrState& st, int n, int w0, int w1, int wantz) {
+    SlabRanges r;
+    r.lc0 = w1;
+    if (wantz) { r.lclim = n; r.rr0 = 0; r.nZ = (n + 15) >> 4; }
+    else { r.lclim = st.ihi + 1 < n ? st.ihi + 1 : n; r.rr0 = st.ilo < w0 ? st.ilo : w0; r.nZ = 0; }
+    r.nL = r.lclim > w1 ? (r.lclim - w1 + 15) >> 4 : 0;
+    r.nR = (w0 - r.rr0 + 15) >> 4;
+    return r;
+}
+
 // strip g of PART 0 (left update: nL strips of 16 columns of H right of the window), PART 1 (right updates: nR strips of 16
 // rows of H above the window, then the strips of Z) or PART 2 (everything: left | right-H | Z)
 template <class T, int PART>
-__device__ __forceinline__ SlabStrip<T> slab_locate(int g, int nL, int nR, cx<T>* H, cx<T>* Z, int n, int w0, int w1) {
+__device__ __forceinline__ SlabStrip<T> slab_locate(int g, const SlabRanges& R, cx<T>* H, cx<T>* Z, int n, int w0) {
     SlabStrip<T> d;
-    if (PART == 2) { if (g < nL) { d.X = H; d.side = 0; d.a0 = w1 + 16 * g; d.lim = n; return d; } g -= nL; }
-    if (PART == 0) { d.X = H; d.side = 0; d.a0 = w1 + 16 * g; d.lim = n; }
-    else if (g < nR) { d.X = H; d.side = 1; d.a0 = 16 * g; d.lim = w0; }
-    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nR); d.lim = n; }
+    if (PART == 2) { if (g < R.nL) { d.X = H; d.side = 0; d.a0 = R.lc0 + 16 * g; d.lim = R.lclim; return d; } g -= R.nL; }
+    if (PART == 0) { d.X = H; d.side = 0; d.a0 = R.lc0 + 16 * g; d.lim = R.lclim; }
+    else if (g < R.nR) { d.X = H; d.side = 1; d.a0 = R.rr0 + 16 * g; d.lim = w0; }
+    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - R.nR); d.lim = n; }
     return d;
 }
 
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 template <class T, int SPW, int PART>
 __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                            QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work, int nslab, int dynamic, int band_on) {
+                                                           unsigned* __restrict__ work, int nslab, int dynamic, int band_on, int wantz) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1101,15 +1101,17 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     const int w0 = st_all[b].w0[ch], w1 = st_all[b].w1[ch];
     const int ww = w1 - w0;
     if (ww <= 0) return;
-    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
+    const SlabRanges RG = slab_ranges(st_all[b], n, w0, w1, wantz);
+    const int nL = RG.nL, nR = RG.nR, nZ = RG.nZ;
     const int S = PART == 0 ? nL : (PART == 1 ? nR + nZ : nL + nR + nZ);
+    if (S <= 0) return;
     const int g0 = gx * (4 * SPW);
     if (PART == 2 && dynamic) { if (*(volatile int*)&st_all[b].strip_next >= S) return; }
     else if (g0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
     if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
-        atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
+        atomicAdd(work, (unsigned)(((long)ww * ww * (wantz ? 2L * n - ww : (long)(RG.lclim > w1 ? RG.lclim - w1 : 0) + (w0 - RG.rr0))) >> 12));
     const cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
     int dense = 0;                            // any nonzero in the blocks the banded product skips?
     for (int e = t; e < QW * QW; e += 256) {
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
         };
         for (int g = claim(); g < S;) {
             const int gn = claim();
-            const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
+            const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
             if (band) {
                 if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
                 else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     for (int i = 0; i < SPW; ++i) {
         const int g = g0 + wave + 4 * i;
         if (g >= S) break;
-        const SlabStrip<T> d = slab_locate<T, PART>(g, nL, nR, H, Z, n, w0, w1);
+        const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
         const bool left = PART == 0 || (PART == 2 && d.side == 0);
         if (band) {
             if (left) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
@@ -1159,74 +1161,6 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
             if (left) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
             else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
         }
-    }
-}
-
-// Off-window update of one step of the LOOK-AHEAD schedule (knob qr_look; one chain per sweep).  The update of step k is cut in two:
-//   phase 0 ("critical")  the first lgc left strips = the columns right of window k that window k+1 covers.  It runs on the group's
-//                         main stream between the two chases (after the remaining update of step k-1, whose rows it shares).
-//   phase 1 ("remaining") all other left strips, the right strips of H and the strips of Z, on the group's SECOND stream, while
-//                         window k+1 is chased: it touches nothing of window k+1 (rows >= w0(k+1) only in columns >= w1(k+1)).
-// Ordering (host side, events): chase k -> critical k -> chase k+1;  remaining k after critical k and remaining k-1;  critical k+1
-// after remaining k.  Everything a step's kernels read (window, U slot, strip counter) sits under the step's parity in QrState, the
-// chase of the next step writes the other parity.  Strips of the remaining update are claimed dynamically.
-template <class T>
-__global__ __launch_bounds__(256, 2) void apply_look_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
-                                                         QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                         unsigned* __restrict__ work, int par, int phase, int band_on) {
-    TRX_DYN_SMEM(smem);
-    T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
-    T* Ui = Ur + QW * MLD;
-    const int b = blockIdx.y;
-    const int w0 = st_all[b].lw0[par], w1 = st_all[b].lw1[par];
-    const int ww = w1 - w0;
-    if (ww <= 0) return;
-    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
-    int gc = st_all[b].lgc[par];
-    if (gc > nL) gc = nL;
-    const int S = phase == 0 ? gc : nL - gc + nR + nZ;
-    if (phase == 0 ? (int)blockIdx.x * 4 >= S : *(volatile int*)&st_all[b].lstrip[par] >= S) return;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (phase == 1 && blockIdx.x == 0 && t == 0) atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
-    const cx<T>* U = Uall + ((long)b * QKC + st_all[b].lus[par]) * QW * QW;
-    int dense = 0;
-    for (int e = t; e < QW * QW; e += 256) {
-        const int k = e >> 6, c = e & 63;
-        cx<T> u(T(0), T(0));
-        if (k < ww && c < ww) u = U[k * QW + c];
-        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
-        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
-    }
-    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);
-    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
-    __syncthreads();
-    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
-    cx<T>* H = Aall + (long)b * mstride;
-    cx<T>* Z = Zall + (long)b * mstride;
-    auto run = [&](int g) {              // strip g of the step's full list: left | right-H | Z
-        const SlabStrip<T> d = slab_locate<T, 2>(g, nL, nR, H, Z, n, w0, w1);
-        if (band) {
-            if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
-        } else {
-            if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
-        }
-    };
-    if (phase == 0) {
-        for (int g = blockIdx.x * 4 + wave; g < S; g += 4 * gridDim.x) run(g);
-        return;
-    }
-    auto claim = [&]() {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(&st_all[b].lstrip[par], 1);
-        return __builtin_amdgcn_readfirstlane(g);
-    };
-    for (int g = claim(); g < S;) {
-        const int gn = claim();
-        run(g + gc);
-        g = gn;
     }
 }
 
@@ -1305,7 +1239,7 @@ __device__ __forceinline__ void slab_strip_tiles(const T* __restrict__ Ur, const
 // stores skip the identity rows / columns (slab_store_pair<FULL>), so nothing outside the real window is rewritten.
 template <class T>
 __global__ __launch_bounds__(256, 2) void apply_window_pipe_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
-                                                                QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall, unsigned* __restrict__ work) {
+                                                                QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall, unsigned* __restrict__ work, int wantz) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1313,10 +1247,12 @@ __global__ __launch_bounds__(256, 2) void apply_window_pipe_kernel(cx<T>* __rest
     const int w0 = st_all[b].w0[0], w1 = st_all[b].w1[0];
     const int ww = w1 - w0;
     if (ww <= 0) return;
-    const int nL = (n - w1 + 15) >> 4, nR = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
-    const int S = nL + nR + nZ;
+    const SlabRanges RG = slab_ranges(st_all[b], n, w0, w1, wantz);
+    const int S = RG.nL + RG.nR + RG.nZ;
+    if (S <= 0) return;
     const int t = threadIdx.x, lane = t & 63;
-    if (blockIdx.x == 0 && t == 0) atomicAdd(work, (unsigned)(((long)ww * ww * (2L * n - ww)) >> 12));
+    if (blockIdx.x == 0 && t == 0)
+        atomicAdd(work, (unsigned)(((long)ww * ww * (wantz ? 2L * n - ww : (long)(RG.lclim > w1 ? RG.lclim - w1 : 0) + (w0 - RG.rr0))) >> 12));
     const int ws0 = w0 < n - QW ? w0 : n - QW;          // origin of the QW-wide frame
     const int sh = w0 - ws0;                            // the real window sits at frame indices [sh, sh + ww)
     const int krange = sh | ((sh + ww) << 8);
@@ -1342,20 +1278,20 @@ __global__ __launch_bounds__(256, 2) void apply_window_pipe_kernel(cx<T>* __rest
     const int gbase = blockIdx.x * 4 * spw + wave;
     const int gend = (blockIdx.x + 1) * 4 * spw < S ? (blockIdx.x + 1) * 4 * spw : S;     // this workgroup's strips: [blockIdx.x*4*spw, gend)
     if (gbase >= gend) return;
-    SlabStrip<T> d0 = slab_locate<T, 2>(gbase, nL, nR, H, Z, n, w0, w1), d1 = d0;
+    SlabStrip<T> d0 = slab_locate<T, 2>(gbase, RG, H, Z, n, w0), d1 = d0;
     cx<T> xa0[8], xb0[8], xa1[8], xb1[8];
     slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
     slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
     for (int g = gbase;; g += 8) {
         const int gb = g + 4, gc = g + 8;
-        d1 = slab_locate<T, 2>(gb < gend ? gb : g, nL, nR, H, Z, n, w0, w1);
+        d1 = slab_locate<T, 2>(gb < gend ? gb : g, RG, H, Z, n, w0);
         slab_load_half<T, true>(d1, 0, n, ws0, QW, lane, xa1);
         slab_load_half<T, true>(d1, 1, n, ws0, QW, lane, xb1);
         __builtin_amdgcn_sched_barrier(0);
         if (d0.side == 0) slab_strip_tiles<T, 0>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
         else slab_strip_tiles<T, 1>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
         if (gb >= gend) break;
-        d0 = slab_locate<T, 2>(gc < gend ? gc : gb, nL, nR, H, Z, n, w0, w1);
+        d0 = slab_locate<T, 2>(gc < gend ? gc : gb, RG, H, Z, n, w0);
         slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
         slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1379,7 +1315,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, look = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1401,8 +1337,7 @@ static QrKnobs& qr_knobs() {
         q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
-        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);
-        q.look = geti("TRX_QR_LOOK", 0, 3, 0);                // 2: look-ahead schedule (off-window update of step k under the chase of step k+1)              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
+        q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1418,16 +1353,7 @@ struct QrLane {
     int* hsum = nullptr;               // pinned host memory, 2 x 4 ints
     int dev = -1;
     bool has_stream = false;
-    hipStream_t s2 = nullptr;          // look-ahead schedule: the stream of the remaining updates (created on first use)
-    hipEvent_t evA[2] = {nullptr, nullptr}, evR[2] = {nullptr, nullptr};   // "critical update of step k done" / "remaining update of step k done", k % 2
 };
-static bool lane_look_ready(QrLane& l) {
-    if (l.s2) return true;
-    if (hipStreamCreateWithFlags(&l.s2, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 2; ++i)
-        if (hipEventCreateWithFlags(&l.evA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.evR[i], hipEventDisableTiming) != hipSuccess) return false;
-    return true;
-}
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
@@ -1466,7 +1392,6 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
-    else if (s == "qr_look") { slot = &k.look; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1474,23 +1399,32 @@ int qr_set_knob(const char* key, int value) {
 }
 
 template <class T>
-int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info) {
+int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info, int wantz) {
     constexpr int LD = QW + 1;
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
     const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
     const size_t sma = sizeof(T) * 2 * QW * MLD + 16;        // + the four per-wave band votes
     auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
-    static std::once_flag attr_once[2];
-    int attr_rc = 0;
-    std::call_once(attr_once[sizeof(T) == 8], [&] {
-        attr_rc = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
+    // opt-in to > 64 KB of dynamic LDS: per (device, dtype), once; a failure is remembered so that no later call launches anyway
+    static std::mutex attr_mu;
+    static int attr_state[64][2];        // 0 = not yet set, 1 = ok, 2 = failed
+    int attr_rc = 0, dev_attr = 0;
+    (void)hipGetDevice(&dev_attr);
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
+        if (stt == 0) {
+            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) || set_max_dyn_smem((const void*)apply_look_kernel<T>, sma) ||
+                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp_of(SM));
-    });
+            stt = r ? 2 : 1;
+        }
+        attr_rc = stt == 2;
+    }
     if (attr_rc) return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
     if (hipMemsetAsync(B.summary, 0, sizeof(int) * 64, s) != hipSuccess) return TRX_ERR_LAUNCH;
@@ -1514,13 +1448,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
     const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
     const int band_on = K.band != 1;
-    // look-ahead schedule (one chain per sweep): see apply_look_kernel.  Opt-in (knob qr_look = 2) until it is measured.
-    const bool look = K.look >= 2 && kc == 1;
-    // A chase workgroup of the look-ahead schedule has to find room on a CU that also holds ONE slab-update workgroup (74 KB of
-    // the 160 KB): with a rotation log of 48 instead of 96 chain steps it needs 85 KB instead of 104 KB.  The first window of a
-    // sweep (62 steps) and a clipped last one then take two launches.
-    const int wmax_look = 48;
-    const size_t smw_look = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * wmax_look * QNS + sizeof(QrState);
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
@@ -1538,7 +1465,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
-        bool have_r;           // look-ahead: a remaining update has been queued on the second stream
     };
     // 4 groups = the number of hardware queues a HIP process gets by default; beyond that streams share queues and serialise
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
@@ -1559,12 +1485,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.b0 = g == 0 ? 0 : grp[g - 1].b0 + grp[g - 1].nb;
         G.summary = B.summary + 8 * g;
         G.done = false;
+        G.issued = 0;
+        G.read = 0;
         G.work = 0;
         G.par = 0;
         G.g = g;
-        G.have_r = false;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
-        if (look && !lane_look_ready(G.lane)) { rc = TRX_ERR_LAUNCH; ++nlanes; break; }
         ++nlanes;
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
@@ -1590,7 +1516,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
           TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
+                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
                      (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
@@ -1604,52 +1530,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary); every further chain
         // enters about 3 steps behind the one ahead.  `bound` is one iteration old, i.e. already a step or so generous, and a sweep
         // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
-        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) + (look ? 2 : 0) : 1;
+        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
         unsigned* wk = (unsigned*)(G.summary + 3);
-        if (look) {
-            // chase k -> critical k -> chase k+1 on the group's stream; remaining k on the second stream (after critical k, before
-            // critical k+1); the prepare kernel that follows the sweep waits for the last remaining update
-            int wgm = (K.wgs ? K.wgs : 448) / G.nb;          // < 2 per CU over the group: the chase of the next step needs CUs of its own
-            wgm = wgm < 1 ? 1 : (wgm > 32 ? 32 : wgm);
-            if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
-            hipStream_t s2 = G.lane.s2;
-            auto remaining = [&](int par) {
-                (void)hipStreamWaitEvent(s2, G.lane.evA[par], 0);
-                { ProfScope p(PROF_QR_APPLY_RIGHT, s2, 0, 0);
-                  TRX_LAUNCH((apply_look_kernel<T>), dim3(wgm, G.nb), dim3(256), sma, s2, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 1, band_on); }
-                (void)hipEventRecord(G.lane.evR[par], s2);
-                G.have_r = true;
-            };
-            // qr_look = 3 (tests): the remaining update of step k is ISSUED after the chase of step k+1 instead of before it -- an
-            // order the events allow just as well.  On the in-order CPU emulator the two issue orders are the two extreme
-            // interleavings of "remaining k" with "chase k+1", so equal results there check that the two really are independent.
-            const bool defer = K.look == 3;
-            int pending = -1;
-            for (int q = 0; q < nwin; ++q) {
-                const int par = G.par;
-                { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-                  TRX_LAUNCH((qr_window_kernel<T, false>), dim3(1, G.nb), dim3(WTHREADS), smw_look, G.s, Ag, mstride, n, stg, Ug, shg, par, (long long*)nullptr, 1, wmax_look); }
-                if (pending >= 0) { remaining(pending); pending = -1; }
-                if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[par ^ 1], 0);
-                TRX_LAUNCH((apply_look_kernel<T>), dim3(1, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, par, 0, band_on);
-                (void)hipEventRecord(G.lane.evA[par], G.s);
-                if (q == 0) {
-                    // the first slot of a sweep applies the unitary of the prepare kernel (AED window / finished small block) where
-                    // there is one: its rows and columns are not related to the first chase window, so nothing of it may overlap
-                    remaining(par);
-                    (void)hipStreamWaitEvent(G.s, G.lane.evR[par], 0);
-                } else if (defer) pending = par;
-                else remaining(par);
-                G.par ^= 1;
-            }
-            if (pending >= 0) remaining(pending);
-            if (G.have_r) (void)hipStreamWaitEvent(G.s, G.lane.evR[G.par ^ 1], 0);
-            return;
-        }
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev, 0, WMAXS);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr, 0, WMAXS); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
@@ -1664,20 +1550,20 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               }
               const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(wgm, G.nb);
               if (kc == 1 && dyn && pipe) {
-                  if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk);
+                  if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wantz);
               } else if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on);
+                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
+                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
+                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
               } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
+                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
               } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
+                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
               } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
+                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
               } }
         }
     };
@@ -1742,6 +1628,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
             if (hipEventRecord(G.lane.ev, G.s) != hipSuccess || hipStreamWaitEvent(s, G.lane.ev, 0) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
             if (hipStreamSynchronize(G.s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
+        } else if (G.issued > 0) {
+            // the host loop runs one iteration ahead: the last iteration queued on the CALLER's stream (empty sweep, prepare, summary
+            // copy into this lane's pinned slot, event) may still be pending.  The lane must not go back to the pool before it has
+            // landed -- a concurrent trx_eig on another host thread could check it out and read the stale summary as its own.
+            if (hipEventSynchronize(G.lane.evs[(G.issued - 1) & 1]) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
         }
         lane_return(G.lane);
     }
@@ -1760,7 +1651,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     return TRX_OK;
 }
 
-template int hessenberg_qr<float>(hipStream_t, const EigBuffers<float>&, int, int, int*);
-template int hessenberg_qr<double>(hipStream_t, const EigBuffers<double>&, int, int, int*);
+template int hessenberg_qr<float>(hipStream_t, const EigBuffers<float>&, int, int, int*, int);
+template int hessenberg_qr<double>(hipStream_t, const EigBuffers<double>&, int, int, int*, int);
 
 }  // namespace trx

@@ -112,11 +112,18 @@ int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>
     }
     int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, B.Z, n, nn, B.X, n, nn, zero, V, n, nn, batch, nullptr, 1);    // X upper triangular: half the K range
     if (rc) return rc;
+    return finish_vectors<T>(s, B, n, batch, V);
+}
+
+template <class T>
+int finish_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* V) {
     TRX_LAUNCH((colnorm_scale_kernel<T>), dim3(cdiv_i(n, 64), batch), dim3(256), 0, s, V, n, (const T*)B.bal_d);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
 
+template int finish_vectors<float>(hipStream_t, const EigBuffers<float>&, int, int, cx<float>*);
+template int finish_vectors<double>(hipStream_t, const EigBuffers<double>&, int, int, cx<double>*);
 template int schur_vectors<float>(hipStream_t, const EigBuffers<float>&, int, int, cx<float>*, cx<float>*);
 template int schur_vectors<double>(hipStream_t, const EigBuffers<double>&, int, int, cx<double>*, cx<double>*);
 

@@ -10,6 +10,7 @@ struct TagData {
     std::vector<hipEvent_t> start, stop;
     std::vector<double> sflops, sbytes;       // algorithmic work of each sampled launch
     int used = 0;          // event pairs in use
+    int open = 0;          // scopes that hold a slot of this tag and have not recorded their stop event yet
     long stride = 1;       // every stride-th launch is sampled (starts at 16 for the two kernels launched ~18000 times per eig call:
                            // an event pair around EVERY such launch cost 2 % of the step time, measured)
     double launches = 0;   // all launches seen while enabled
@@ -31,7 +32,9 @@ int prof_begin(int tag, hipStream_t s, double flops, double bytes) {
     t.bytes += bytes;
     if (idx % t.stride != 0) return -1;
     if (t.used >= POOL) {
-        // pool full: keep the samples of the even multiples of the stride (slots 0, 2, 4, ...), double the stride
+        // pool full: keep the samples of the even multiples of the stride (slots 0, 2, 4, ...), double the stride.  The compaction moves
+        // event pairs to other slots, so it waits until no scope (of another host thread) still holds a slot handle of this tag.
+        if (t.open > 0) return -1;
         for (int i = 0; 2 * i < t.used; ++i) {
             std::swap(t.start[i], t.start[2 * i]);
             std::swap(t.stop[i], t.stop[2 * i]);
@@ -54,12 +57,14 @@ int prof_begin(int tag, hipStream_t s, double flops, double bytes) {
     t.sflops[slot] = flops;
     t.sbytes[slot] = bytes;
     hipEventRecord(t.start[slot], s);
+    t.open += 1;
     return slot;
 }
 
 void prof_end(int tag, int slot, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_mu);
     hipEventRecord(g_tags[tag].stop[slot], s);
+    g_tags[tag].open -= 1;
 }
 
 void prof_add_work(int tag, double flops, double bytes) {
@@ -80,6 +85,7 @@ extern "C" int trx_prof_reset(void) {
     for (int i = 0; i < PROF_NTAGS; ++i) {
         TagData& t = g_tags[i];
         t.used = 0;
+        t.open = 0;
         t.stride = (i == PROF_QR_WINDOW || i == PROF_QR_APPLY_RIGHT) ? 16 : 1;
         t.launches = t.flops = t.bytes = 0;
     }
@@ -105,6 +111,6 @@ extern "C" int trx_prof_get(int tag, double* out) {
 
 extern "C" const char* trx_prof_tag_name(int tag) {
     static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "qr_prepare_kernel", "apply_window_kernel",
-                                            "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel"};
+                                            "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel", "invit_solve_kernel"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }
