@@ -39,6 +39,8 @@ inline hipError_t hipPeekAtLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 16; return 0; }      // a small "chip": 8 XCDs x 2 CUs
 static const unsigned hipHostMallocDefault = 0;
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 2; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
@@ -362,8 +364,14 @@ inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline void sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
 inline void sincosf(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
 inline void sincospi(double x, double* s, double* c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+
+// direct global -> LDS load (torcwa_amd/csrc/common.hpp): the emulator copies at once, so the wait is empty
+#define TRX_LDS_DMA16(gsrc_lane, lds_wave_base) std::memcpy((char*)(lds_wave_base) + 16 * (threadIdx.x & 63), (const void*)(gsrc_lane), 16)
+#define TRX_WAIT_VMCNT(n) ((void)0)
 
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 namespace hipemu {

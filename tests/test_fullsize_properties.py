@@ -84,3 +84,105 @@ def test_native_c64_precision_is_reference_class():
     assert np.abs(hi - ref).max() / np.abs(ref).max() < 1e-5
     assert np.abs(nat - ref).max() / np.abs(ref).max() < 2e-2
     print("native-c64 rel err:", np.abs(nat - ref).max() / np.abs(ref).max(), " high:", np.abs(hi - ref).max() / np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] at its real size: 4 patterned layers, order [21,21] (n = 3698) -- the dense layer*layer Redheffer
+# product of /root/reference/torcwa/rcwa.py:1283-1306 on the stack of example/Example1-1.ipynb:159-177
+# ---------------------------------------------------------------------------------------------------------------------------
+def _lossless_4layer(B, lam, pick=None):
+    import torcwa_amd
+    from torcwa_amd.sweep import rectangle_density
+    dev = torch.device("cuda")
+    eps_core = torch.linspace(5.0, 6.5, B, dtype=torch.float64, device=dev)
+    if pick is not None:
+        eps_core = eps_core[pick:pick + 1]
+    sim = torcwa_amd.BatchedRCWA(torch.full((eps_core.shape[0],), 1.0 / lam, dtype=torch.float64), [21, 21], [300., 300.], dtype=torch.complex128,
+                                 keep_coupling=False)
+    sim.add_input_layer(eps=2.1)
+    sim.set_incident_angle(0.1, 0.25)
+    for th in (0., 30., 60., 90.):
+        d = rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., theta=th / 180 * np.pi, dtype=torch.float64, device=dev)
+        sim.add_layer(200., d[None] * eps_core[:, None, None] + (1. - d[None]) * 2.56)
+    sim.solve_global_smatrix()
+    return sim
+
+
+def test_config3_four_layer_stack_at_order_21():
+    """Energy conservation of the lossless 4-layer stack at n = 3698 (three dense star products + the half-space one), and the
+    lock-step batch against one of its points solved alone."""
+    simB = _lossless_4layer(2, 520.0)
+    assert simB.engine.failures() == 0
+    for pol in ("p", "s"):
+        p = power_sum(simB, pol)
+        assert np.abs(p - 1.0).max() < 1e-8, (pol, p)
+    orders = [[0, 0], [1, 0], [0, -1], [-1, 1]]
+    tB = simB.S_parameters(orders, polarization="xx").cpu().numpy()
+    sim1 = _lossless_4layer(2, 520.0, pick=1)
+    t1 = sim1.S_parameters(orders, polarization="xx").cpu().numpy()
+    assert np.abs(t1[0] - tB[1]).max() < 1e-9
+
+
+def test_dense_redheffer_equals_halfspace_path_at_order_21():
+    """trx_redheffer (dense * dense, one LU with 2n right-hand sides) against trx_redheffer_halfspace (dense * 2x2-block-diagonal in O(n^2)
+    combinations + one LU) on the same operands at n = 3698: a patterned layer's S-matrix times a homogeneous layer's, once with the
+    homogeneous blocks kept as diagonals and once densified (rcwa.py:1283-1296)."""
+    import torcwa_amd
+    from torcwa_amd.sweep import rectangle_density
+    dev = torch.device("cuda")
+    sim = torcwa_amd.BatchedRCWA(torch.tensor([1.0 / 610.0], dtype=torch.float64), [21, 21], [300., 300.], dtype=torch.complex128, keep_coupling=False)
+    sim.add_input_layer(eps=2.1)
+    sim.set_incident_angle(0.2, 0.1)
+    d = rectangle_density(300, 300, 300., 300., 180., 100., 150., 150., theta=0.3, dtype=torch.float64, device=dev)
+    sim.add_layer(180., (d * (12.0 + 0.5j) + (1. - d))[None].to(torch.complex128))
+    sim.add_layer(90., 2.2)                                   # homogeneous: block-diagonal closed form
+    Sp, Sh = sim._layer_S(0), sim._layer_S(1)
+    assert sim._is_bd(Sh) and not sim._is_bd(Sp)
+    S_bd, _ = sim._star(Sp, Sh, [[], []], [[], []])
+    Sh_dense = [blk.dense().to(torch.complex128).contiguous() for blk in Sh]
+    S_dn, _ = sim._RS_prod(Sp, Sh_dense, [[], []], [[], []])
+    for k in range(4):
+        a, b = S_bd[k], S_dn[k]
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-10, k
+    # and from the other side
+    S_bd2, _ = sim._star(Sh, Sp, [[], []], [[], []])
+    S_dn2, _ = sim._RS_prod(Sh_dense, Sp, [[], []], [[], []])
+    for k in range(4):
+        assert float((S_bd2[k] - S_dn2[k]).abs().max() / S_dn2[k].abs().max()) < 1e-10, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at its real size: order [25,25] (n = 5202), complex128, forward + adjoint through the stabilised
+# eigendecomposition gradient (example/Example6.ipynb:68-79 at the BASELINE order; torcwa/torch_eig.py:19-44)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_config5_forward_adjoint_at_order_25():
+    """The adjoint gradient of the figure of merit (power into the +1 order) with respect to the density, checked against a central
+    finite difference along a random direction."""
+    import bench
+    dev = torch.device("cuda")
+    eng = None
+    rho0 = bench.make_inputs_topopt(dev)
+    fom = bench.run_step_topopt(rho0, [25, 25], eng)
+    import torcwa_amd
+
+    def fom_of(rho):
+        sim = torcwa_amd.rcwa(freq=1 / 532., order=[25, 25], L=[700., 300.], dtype=torch.complex128, device=dev, stable_eig_grad=True)
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        sim.add_layer(thickness=300., eps=rho * bench.TOPOPT_EPS + (1. - rho))
+        sim.solve_global_smatrix()
+        t = [sim.S_parameters(orders=[1, 0], direction='forward', port='transmission', polarization=p, ref_order=[0, 0]) for p in ('xx', 'yx', 'xy', 'yy')]
+        return sum(torch.abs(v) ** 2 for v in t).sum()
+
+    rho = rho0.clone().requires_grad_(True)
+    f = fom_of(rho)
+    f.backward()
+    assert abs(float(f) - float(fom.real)) < 1e-12 * max(1.0, abs(float(f)))
+    g = rho.grad
+    d = torch.randn(rho0.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dev)
+    h = 1e-4
+    with torch.no_grad():
+        fp, fm = fom_of(rho0 + h * d), fom_of(rho0 - h * d)
+    fd = float(fp - fm) / (2 * h)
+    ad = float((g * d).sum())
+    assert abs(ad - fd) / abs(fd) < 1e-5, (ad, fd)

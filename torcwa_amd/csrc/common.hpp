@@ -13,6 +13,19 @@
 #define TRX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #endif
 
+#ifndef TRX_LDS_DMA16
+// Direct global -> LDS load of 16 bytes per lane (gfx950 global_load_lds_dwordx4): lane L's 16 bytes land at lds_wave_base + 16 L
+// (lds_wave_base wave-uniform; placement and ordering pinned on hardware by tests/micro/lds_dma.hip).  No destination registers, and --
+// being inline assembly -- invisible to the compiler's own wait-count bookkeeping: the kernel waits with TRX_WAIT_VMCNT(n) ("at most
+// n younger vector-memory operations of this wave still in flight") before a barrier that publishes the data.  (The compiler's builtin
+// for the same instruction makes it wait for ALL of them in front of every later LDS read, which would undo the prefetch.)
+#define TRX_LDS_DMA16(gsrc_lane, lds_wave_base)                                                                          \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"((const void*)(gsrc_lane)),   \
+                 "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_wave_base)))                                    \
+                 : "memory", "m0")
+#define TRX_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+
 #define TRX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel), grid, block, shmem, stream, __VA_ARGS__)
 

@@ -65,7 +65,7 @@ static int eig_vec_env() {
     const int v = e ? atoi(e) : 0;
     return (v >= 0 && v <= 2) ? v : 0;
 }
-static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (inverse iteration), 1 Schur vectors, 2 inverse iteration
+static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
 int eig_set_knob(const char* key, int value) {
     if (std::string(key) != "eig_vec" || value < 0 || value > 2) return TRX_ERR_ARG;
     g_eig_vec = value;
@@ -93,7 +93,10 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
     // Eigenvector route (knob eig_vec: 0 = automatic, 1 = Schur vectors, 2 = inverse iteration).  Inverse iteration (eig_invit.hip): the
     // QR phase runs for eigenvalues only -- a third of the off-window work and no Z -- and each eigenvector costs one O(n^2) solve.
-    const bool invit = g_eig_vec != 1 && n <= INVIT_NMAX && n >= 2;
+    // Automatic = Schur vectors: measured on MI355X (round 3, profiles/r03_invit_route.txt) the eigenvalues-only QR phase is 0.5 s shorter
+    // per 128-matrix batch at n = 1922, but the solve kernel (a latency-bound recurrence of n barrier-separated steps per eigenvalue
+    // group, 7 TF-equivalent of fp64 vector work) takes 1.05 s, and the route loses at every batch size from 1 to 128.
+    const bool invit = g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2;
     if (invit) {
         rc = invit_prepare<T>(s, B, n, batch);
         if (rc) return rc;
@@ -186,7 +189,8 @@ extern "C" int trx_tuning(const char* key, int value) {
     if (!key) return TRX_ERR_ARG;
     int rc = trx::qr_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::lu_set_knob(key, value);
-    return rc == TRX_OK ? rc : trx::eig_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
+    return rc == TRX_OK ? rc : trx::invit_set_knob(key, value);
 }
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {

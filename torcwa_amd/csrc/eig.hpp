@@ -65,6 +65,8 @@ template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, 
 // updates are restricted to the active diagonal block, A is NOT a Schur form afterwards and Z is not touched)
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info, int wantz);
 int qr_set_knob(const char* key, int value);
+int eig_set_knob(const char* key, int value);
+int invit_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 // V <- D V (undo of the balancing) with unit 2-norm columns
 template <class T> int finish_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* V);

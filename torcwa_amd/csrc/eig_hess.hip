@@ -9,6 +9,7 @@
 //                     v broadcast from LDS)  -- HBM-bound, n^3/3 element reads per matrix in total.
 //   gemm              all block updates (right/left trailing updates and the Z accumulation).
 #include "eig.hpp"
+#include <cstdlib>
 #include "prof.hpp"
 
 namespace trx {
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall,
 }
 
 // Yraw[r, c] = sum_{q>j} A[r, q] * V[q, c]   for r in [r0, n)
-template <class T>
+// RPW rows per wave and pass: the v element read from LDS serves all of them, and RPW row loads per lane are in flight (2: measured
+// 5.07 TB/s in situ at the bench shape; 4 doubles the bytes in flight per CU, which is what an 8 TB/s stream with ~1 us of latency asks for)
+template <class T, int RPW>
 __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c,
                                                          const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, int rows_per_block) {
     TRX_DYN_SMEM(smem);
@@ -167,24 +170,29 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rbeg = r0 + blockIdx.x * rows_per_block;
-    // two rows per wave and pass: the v element read from LDS serves both, and twice as many row loads are in flight
-    for (int rr = 2 * wid; rr < rows_per_block; rr += 2 * nw) {
+    for (int rr = RPW * wid; rr < rows_per_block; rr += RPW * nw) {
         const int ra = rbeg + rr;
         if (ra >= n) break;
-        const bool two = (rr + 1 < rows_per_block) && (ra + 1 < n);
-        const cx<T>* rowa = A + (long)ra * n + j + 1;
-        const cx<T>* rowb = two ? rowa + n : rowa;
-        cx<T> acca(T(0), T(0)), accb(T(0), T(0));
+        const cx<T>* row[RPW];
+        cx<T> acc[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const bool ok = (rr + q < rows_per_block) && (ra + q < n);
+            row[q] = A + (long)(ok ? ra + q : ra) * n + j + 1;       // a missing row re-reads the first one (its sum is not stored)
+            acc[q] = cx<T>(T(0), T(0));
+        }
         for (int i = lane; i < len; i += 64) {
             const cx<T> vi = v[i];
-            cfma(acca, rowa[i], vi);
-            cfma(accb, rowb[i], vi);
+            cx<T> a[RPW];
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) a[q] = row[q][i];
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) cfma(acc[q], a[q], vi);
         }
-        acca.x = wave_sum(acca.x); acca.y = wave_sum(acca.y);
-        accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y);
-        if (lane == 0) {
-            Y[(long)ra * HNB + c] = acca;
-            if (two) Y[(long)(ra + 1) * HNB + c] = accb;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            acc[q].x = wave_sum(acc[q].x); acc[q].y = wave_sum(acc[q].y);
+            if (lane == 0 && (rr + q < rows_per_block) && (ra + q < n)) Y[(long)(ra + q) * HNB + c] = acc[q];
         }
     }
 }
@@ -217,6 +225,11 @@ __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ 
 
 }  // namespace
 
+static int hess_rpw() {
+    static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return x == 4 ? 4 : 2; }();
+    return v;
+}
+
 template <class T>
 int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     const cx<T> one(T(1), T(0)), mone(T(-1), T(0)), zero(T(0), T(0));
@@ -224,8 +237,10 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     cx<T>*A = B.A, *Z = B.Z, *V = B.Vp, *Y = B.Yp, *Tm = B.Tp, *W = B.W1, *W2 = B.W2;
     TRX_LAUNCH((set_identity_batched<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, Z, n);
     const size_t sm_col = sizeof(cx<T>) * ((size_t)n + HRG * HNB + HNB) + sizeof(T) * 16;
-    if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T>, sizeof(cx<T>) * (size_t)n))
+    if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sizeof(cx<T>) * (size_t)n) ||
+        set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sizeof(cx<T>) * (size_t)n))
         return TRX_ERR_LAUNCH;
+    const int rpw = hess_rpw();
     for (int p0 = 0; p0 < n - 2; p0 += HNB) {
         const int ib = (n - 2 - p0 < HNB) ? (n - 2 - p0) : HNB;
         const int r0 = p0 + 1, nr = n - r0;
@@ -242,8 +257,12 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
                 const int rpb = few ? 16 : 64, gthreads = few ? 512 : 256;
                 // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
                 ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
-                TRX_LAUNCH((hess_gemv_kernel<T>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
-                           (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
+                if (rpw == 4 && !few)
+                    TRX_LAUNCH((hess_gemv_kernel<T, 4>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
+                               (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
+                else
+                    TRX_LAUNCH((hess_gemv_kernel<T, 2>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
+                               (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
             }
         }
         int rc;

@@ -9,6 +9,7 @@
 //   trsm_lower_kernel    U12 = L11^-1 A12      (one thread per column, L11 broadcast from LDS)
 //   gemm                 A22 -= L21 U12
 #include "common.hpp"
+#include <cstdlib>
 #include "prof.hpp"
 #include <string>
 
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 constexpr int NBO = 8 * NB;
 
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
-static int g_lu_split_batch = 0;          // 0 = automatic (2): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
+static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
+static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (2): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
 int lu_set_knob(const char* key, int value) {
     const std::string k(key);
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
