@@ -255,7 +255,8 @@ def layer_solve_roof(n, precision):
     return out
 
 
-_BOUND = {"gemm_mfma_kernel<N,N>": "mfma", "gemm_mfma_kernel<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm"}
+_BOUND = {"gemm_mfma_kernel<N,N>": "mfma", "gemm_mfma_kernel<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm",
+          "invit_solve_kernel": "mfma"}      # fp64 VECTOR FMAs: on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TF)
 
 
 def roofline(engine, args, elapsed, steps, n, units_per_step):
@@ -289,6 +290,12 @@ def roofline(engine, args, elapsed, steps, n, units_per_step):
             # one wave / one workgroup per matrix, dependent chain of small steps: no meaningful flop or byte rate
             k.update(bound="hbm", achieved=0.0, peak=PEAK_HBM_GBS, unit="GB/s", note="latency-bound (one wave or workgroup per matrix)")
         k["frac"] = k["achieved"] / k["peak"]
+        if name in ("apply_window_kernel", "gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>") and args.precision == "high" and k["achieved"] > 0:
+            # fp64 path: 3M complex product, three real MFMAs where the 8-flops-per-complex-MAC count has four
+            k["issued_mfma_tflops"] = 0.75 * k["achieved"]
+            k["issued_mfma_frac"] = 0.75 * k["frac"]
+            k["flop_count_note"] = "achieved counts 8 real flops per complex MAC (TF-equivalent); the 3M product issues 6, so the matrix pipe is at issued_mfma_frac"
+        k.update(profile_fracs(k, args, k["peak"]))
         kernels.append(k)
     kernels.sort(key=lambda k: -k["est_total_ms_per_step"])
     if not kernels:
@@ -308,26 +315,62 @@ def roofline(engine, args, elapsed, steps, n, units_per_step):
     return dom
 
 
+PROFILE_TAG = "r03"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
+
+
+def profile_fracs(k, args, peak):
+    """The same kernel's roofline fraction recomputed from the COMMITTED profiles, so that the line and profiles/ can be held against each
+    other: `frac_rocprof` = algorithmic work per launch / the rocprofv3 --kernel-trace average duration (in situ, kernels of the other
+    iteration groups running next to it), `frac_alone` = the same with the duration from the --pmc passes (rocprofv3 serialises kernels
+    there).  Both are refused unless the profile was taken on the same kernel sources (hash of torcwa_amd/csrc) at this batch size."""
+    out = {}
+    work = k.get("algorithmic_flops_per_launch") if k.get("bound") == "mfma" else k.get("algorithmic_bytes_per_launch")
+    if not work or args.config != 2:
+        return out
+    name = k["kernel"]
+    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float")}.get(name, name.split("<")[0])
+    for field, fn, dur in (("frac_rocprof", "%s_kernel_profile.json" % PROFILE_TAG, lambda v: v["avg_us"]),
+                           ("frac_alone", "%s_pmc_bench.json" % PROFILE_TAG, lambda v: 1e3 * v["ms_total"] / max(v["launches"], 1))):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except (OSError, ValueError):
+            out[field], out[field + "_note"] = None, "profiles/%s not committed" % fn
+            continue
+        if prof.get("csrc_sha16") != csrc_sha16() or prof.get("batch") != args.batch:
+            out[field], out[field + "_note"] = None, "profiles/%s was taken on other kernel sources or another batch size: refused" % fn
+            continue
+        kk = [v for k_, v in prof.get("kernels", {}).items() if k_.startswith(key)]
+        if not kk:
+            out[field], out[field + "_note"] = None, "kernel not in profiles/%s" % fn
+            continue
+        n_l = sum(v["launches"] for v in kk)
+        avg_us = sum(dur(v) * v["launches"] for v in kk) / n_l
+        rate = work / (avg_us * 1e-6) / (1e12 if k.get("bound") == "mfma" else 1e9)
+        out[field] = rate / peak
+        out[field + "_note"] = "%.1f us average over %d launches in profiles/%s" % (avg_us, n_l, fn)
+    return out
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot
     be collected from inside this process).  Accepted only when the summary was taken on the SAME kernel sources (hash of
     torcwa_amd/csrc) and at this batch size -- otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+    path = os.path.join(ROOT, "profiles", "%s_pmc_bench.json" % PROFILE_TAG)
     try:
         pmc = json.load(open(path))
     except (OSError, ValueError):
         return None, "no PMC summary committed for this round"
     if pmc.get("csrc_sha16") != csrc_sha16():
-        return None, "profiles/r02_pmc_bench.json was taken on other kernel sources (csrc hash %s != %s): refused" % (pmc.get("csrc_sha16"), csrc_sha16())
+        return None, "profiles/r03_pmc_bench.json was taken on other kernel sources (csrc hash %s != %s): refused" % (pmc.get("csrc_sha16"), csrc_sha16())
     if pmc.get("batch") != args.batch or args.config != 2:
-        return None, "profiles/r02_pmc_bench.json was taken at another workload"
+        return None, "profiles/r03_pmc_bench.json was taken at another workload"
     key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float")}.get(kernel, kernel.split("<")[0])
     kk = [v for k_, v in pmc.get("kernels", {}).items() if k_.startswith(key)]
     if not kk:
         return None, "kernel not in the PMC summary"
     tot = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk)
     return tot / sum(v["launches"] for v in kk), ("HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of the same command, "
-                                                  "same kernel sources): profiles/r02_pmc_bench.json")
+                                                  "same kernel sources): profiles/r03_pmc_bench.json")
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -388,7 +431,10 @@ def main():
         # lock-step chunk: the 128-point sweep of config 2 is one chunk; the 512 points per GPU of config 4 go in chunks of 256
         # (156 GB allocated / 208 GB reserved of the 288 GB; measured 31.6 vs 28.6 layer-solves/s with chunks of 128); the 4-layer
         # stack of config 3 at n = 3698 in chunks of 32 (144 GiB peak)
-        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 32, 4: 256, 5: 1}[args.config]))
+        # config 3: with the streaming cascade (one layer resident) 64 points of the 4-layer stack take 228 GB allocated / 247 GB reserved of
+        # the 288 GB (3.96 vs 3.44 layer-solves/s in chunks of 32: 114 GB); a smaller device falls back to 32
+        big = EMU or torch.cuda.get_device_properties(device).total_memory >= 280e9
+        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 64 if big else 32, 4: 256, 5: 1}[args.config]))
         out = None
         for w in range(warmup):
             try:

@@ -71,15 +71,33 @@ size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
 
-/* Tuning knobs of the QR phase of trx_eig (no reference counterpart).  Defaults are chosen from the batch size; the environment
- * variables TRX_QR_GROUPS / TRX_SLAB_SPW / TRX_QR_AED / TRX_QR_NIBBLE / TRX_QR_MOVES / TRX_QR_CHAINS are read ONCE per process as
- * initial values.  key: "qr_groups" (iteration groups, 1-8), "slab_spw" (strips per wave of the off-window update: 1, 2, 4),
- * "qr_aed" (AED window, 16-64), "qr_nibble" (0-100), "qr_moves" (AED reordering bound), "qr_chains" (bulge chains per sweep, 1-3),
- * "slab_band" (1 = dense window unitary always; default: the off-window update skips the structurally zero blocks of a chain unitary),
- * "lu_split" (LU panels of 1-2 matrices are factored by several workgroups per matrix while at least this many rows remain; 0 = 1024,
- * 1 = never), "lu_split_batch" (largest batch that uses it; 0 = 2), "qr_look" (2 = look-ahead schedule of the QR sweeps: the off-window
- * update of window step k runs on a second stream while step k+1 is chased; 3 = the same with the other legal issue order, for tests);
- * value 0 = automatic.  Results do not depend on any of them (tests/test_eig.py).  Returns TRX_OK or TRX_ERR_ARG. */
+/* Tuning knobs of libtrx (no reference counterpart).  Results do not depend on any of them (tests/test_eig.py, tests/test_blocks.py); they
+ * select code paths.  Knobs are process-global and unsynchronised: trx_tuning must not race with a running trx_eig / trx_lu_solve.  The
+ * environment variables named below are read ONCE per process as initial values.  Returns TRX_OK, or TRX_ERR_ARG for an unknown key or a
+ * value out of range.  Unless stated otherwise value 0 = automatic (chosen from n and the batch size).
+ *   QR phase of trx_eig
+ *   "qr_groups"   1-8   iteration groups on their own streams (TRX_QR_GROUPS)        auto: 4 (batch >= 64), 2 (batch >= 8), 1
+ *   "qr_aed"      16-64 aggressive-early-deflation window (TRX_QR_AED)                auto: 64 (batch >= 64 or <= 2), else 48
+ *   "qr_chains"   1-3   bulge chains per sweep (TRX_QR_CHAINS)                        auto: 1, and 3 for batch <= 2
+ *   "qr_nibble"   0-100 LITERAL percentage, default 100 (TRX_QR_NIBBLE): an AED that deflated less than this share of its window is
+ *                       followed by a sweep in the same outer iteration; 0 switches that sweep off.  No automatic value.
+ *   "qr_moves"    0-64  LITERAL bound, default 12 (TRX_QR_MOVES): undeflatable eigenvalues an AED moves out of the way; 0 = no reordering.
+ *   "slab_spw"    1, 2, 4  strips per wave of the off-window update with static strips (TRX_SLAB_SPW)     auto: 4 (batch >= 64), else 2
+ *   "slab_dyn"    1 static / 2 dynamically claimed strips (TRX_SLAB_DYN)              auto: dynamic for groups of >= 16 matrices
+ *   "slab_wgs"    32-4096 workgroups per dynamic off-window launch (TRX_SLAB_WGS)     auto: 512
+ *   "slab_pipe"   2 = software-pipelined off-window kernel (TRX_SLAB_PIPE)            auto: off (measured slower)
+ *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chain unitary
+ *   Eigenvector route of trx_eig
+ *   "eig_vec"     1 = Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR phase (TRX_EIG_VEC)
+ *                       auto: Schur vectors (measured faster at every batch size); trx_eig_ws_bytes depends on this knob
+ *   "invit_cfg"   0-6   layout of the inverse-iteration kernel (TRX_INVIT_CFG): 0/1 512 threads, register prefetch 2 deep; 2: 3 deep;
+ *                       3: 1 deep; 4: 1024 threads; 5 / 6: 1024 / 512 threads with the direct-to-LDS column ring
+ *   "invit_ring"  1-3 (register variants) or 3-4 (ring variants) columns of H resident in LDS;  "invit_wpl" 1, 2, 4, 8: minimum waves
+ *                       per eigenvalue (tests);  "invit_xcd" 1 = plain 2-D grid instead of the XCD-aware launches;  "invit_dbg": timing experiments
+ *   LU (trx_lu_solve, trx_inverse and everything built on them)
+ *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
+ *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
+ *   Hessenberg reduction: TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
 int trx_tuning(const char* key, int value);
 
 /* Adjoint of the eigendecomposition: torcwa/torch_eig.py:19-44 (`Eig.backward`, the Lorentzian-broadened formula)

@@ -200,8 +200,27 @@ def excerpt(path, at_frac=0.55, span_us=1500.0):
             print(f"  s{sid}  {(a - lo) / 1e3:9.1f}  {(b - a) / 1e3:8.1f}  {nm.split('<')[0]:24s} ({gx},{gy})")
 
 
+def to_json(path, out, batch, command):
+    """Per-kernel averages of the trace as JSON, stamped with the hash of the kernel sources (bench.py reads it back for the
+    `frac_rocprof` figure of its roofline block and refuses it on other sources)."""
+    import json
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha16
+    agg = {}
+    for name, start, end in sqlite3.connect(path).cursor().execute("select name, start, end from kernels"):
+        a = agg.setdefault(short(name), [0, 0])
+        a[0] += 1
+        a[1] += end - start
+    js = {"csrc_sha16": csrc_sha16(), "batch": int(batch), "command": command,
+          "kernels": {k: {"launches": a[0], "avg_us": a[1] / a[0] / 1e3, "total_ms": a[1] / 1e6} for k, a in agg.items()}}
+    json.dump(js, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "--excerpt":
+    if len(sys.argv) > 4 and sys.argv[2] == "--json":
+        to_json(sys.argv[1], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
+    elif len(sys.argv) > 2 and sys.argv[2] == "--excerpt":
         excerpt(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else 0.55)
     elif len(sys.argv) > 2 and sys.argv[2] == "--concurrency":
         concurrency(sys.argv[1])

@@ -8,6 +8,7 @@ rm -rf /tmp/tr_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/tr_$TAG -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_stderr.log
 DB=$(find /tmp/tr_$TAG -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py $DB 45 > $R/gpurun_out/${TAG}_kernel_stats.txt
+python $R/profiles/kernel_stats.py $DB --json $R/gpurun_out/${TAG}_kernel_profile.json 128 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 python $R/profiles/kernel_stats.py $DB --phases > $R/gpurun_out/${TAG}_phases.txt
 python $R/profiles/kernel_stats.py $DB --gaps-frac 0.55 > $R/gpurun_out/${TAG}_gaps.txt
 python $R/profiles/kernel_stats.py $DB --concurrency > $R/gpurun_out/${TAG}_concurrency.txt 2>&1

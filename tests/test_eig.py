@@ -227,7 +227,7 @@ def test_eig_vector_routes_agree(backend):
     sweeps of several window steps, interior deflations and a multi-wave inverse-iteration layout: same eigenvalues, both pass the
     residual / conditioning checks, and the eigenvectors agree up to a phase."""
     be = get_backend(backend)
-    n, batch = (136, 2) if backend == "emu" else (1100, 3)
+    n, batch = (136, 2) if backend == "emu" else (700, 2)
     A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
     A[1] = 0.3 * A[1] + np.diag(np.linspace(-15, 15, n)).astype(np.complex128)
     res = {}
@@ -254,7 +254,9 @@ def test_eig_inverse_iteration_layouts(backend, knobs):
     512-thread workgroups): forced multi-wave layouts and the alternative slot / thread counts at a size with several slots per lane --
     cross-wave pivot publication, column staging by the whole workgroup, padding eigenvalue groups -- give the same result quality."""
     be = get_backend(backend)
-    n, batch = (150, 1) if backend == "emu" else (700, 3)
+    n, batch = (150, 1) if backend == "emu" else (600, 2)
+    if backend == "gpu" and knobs in (dict(invit_wpl=2), dict(invit_cfg=2, invit_ring=1)):
+        pytest.skip("gpu time budget: covered by the emulator run of the same case")
     A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
     try:
         _set_knobs(be, eig_vec=2, **knobs)

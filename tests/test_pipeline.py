@@ -218,8 +218,8 @@ def test_homogeneous_layers_block_diagonal_path(backend, stack):
     freq = torch.tensor([1 / 500., 1 / 590.], dtype=torch.float64)
     hom = [(60., 2.3 + 0.1j, 1.0), (35., 1.7, 1.2)]
     res = []
-    for keep in (False, True):
-        sim = torcwa_amd.BatchedRCWA(freq, order, L, dtype=torch.complex128, engine=eng, keep_coupling=keep)
+    for keep, fold in ((False, False), (True, False), (False, True)):       # fold: the sweep drivers' streaming cascade (one layer resident)
+        sim = torcwa_amd.BatchedRCWA(freq, order, L, dtype=torch.complex128, engine=eng, keep_coupling=keep, fold_layers=fold)
         if stack != "h_only":
             sim.add_input_layer(eps=2.1)
             sim.add_output_layer(eps=1.4)
@@ -235,5 +235,6 @@ def test_homogeneous_layers_block_diagonal_path(backend, stack):
         sim.solve_global_smatrix()
         res.append([sim.S_parameters([[0, 0], [1, 0], [0, -1]], direction=dr, port=pt, polarization=pol).cpu().numpy()
                     for dr, pt in (("f", "t"), ("f", "r"), ("b", "t"), ("b", "r")) for pol in ("xx", "yx", "ps")])
-    for a, b in zip(*res):
+    for a, b, c in zip(*res):
         assert np.abs(a - b).max() < 1e-10
+        assert np.abs(c - b).max() < 1e-10

@@ -71,7 +71,7 @@ def _halfspace_V(kx, ky, epsmu):
 class BatchedRCWA:
     def __init__(self, freq, order, L, *, batch=None, dtype=torch.complex64, device=None, stable_eig_grad=True,
                  avoid_Pinv_instability=False, max_Pinv_instability=0.005, precision="high", engine=None,
-                 keep_coupling=True):
+                 keep_coupling=True, fold_layers=False):
         if dtype != torch.complex64 and dtype != torch.complex128:                      # rcwa.py:37-41
             warnings.warn("Invalid simulation data type. Set as torch.complex64.", UserWarning)
             dtype = torch.complex64
@@ -88,6 +88,11 @@ class BatchedRCWA:
         self.Pinv_instability = [] if self.avoid_Pinv_instability else None
         self.Qinv_instability = [] if self.avoid_Pinv_instability else None
         self.keep_coupling = keep_coupling
+        # fold_layers (sweep drivers; needs keep_coupling=False): every layer's S-matrix is folded into the running cascade as soon as it
+        # exists and is then dropped together with the layer's convolution matrix, so a K-layer stack holds ONE layer at a time instead
+        # of K (configs[2]: 4 layers at n = 3698).  The per-layer attributes of such a solver are None.
+        self.fold_layers = bool(fold_layers) and not keep_coupling
+        self._running = None
 
         if batch is None:
             batch = freq.numel() if (torch.is_tensor(freq) and freq.dim() > 0) else (len(freq) if isinstance(freq, (list, tuple)) else 1)
@@ -195,6 +200,7 @@ class BatchedRCWA:
 
         if eps_h and mu_h and not diff and not self.keep_coupling:
             self._add_homogeneous_layer_bd(thickness, self._bvec(eps), self._bvec(mu))
+            self._fold_last_layer()
             return
         # Sweep drivers (keep_coupling=False) with a homogeneous mu never read P, Q, the dense mu matrices or, after the layer's
         # S-matrix, the mode matrices W, V: A = PQ and V = P^-1 W Kz come from E directly (trx_build_a / trx_hmodes).  Not building
@@ -251,6 +257,19 @@ class BatchedRCWA:
             self._solve_layer_smatrix_diff()
         else:
             self._solve_layer_smatrix()
+        self._fold_last_layer()
+
+    def _fold_last_layer(self):
+        if not self.fold_layers or getattr(self, "_diff", False):
+            return
+        i = self.layer_N - 1
+        S = self._layer_S(i)
+        if self._running is None:
+            self._running = S
+        else:
+            self._running, _ = self._star(self._running, S, [[], []], [[], []])
+        self.layer_S11[i] = self.layer_S21[i] = None
+        self.eps_conv[i] = None
 
     def _add_homogeneous_layer_bd(self, thickness, eps_s, mu_s):
         """Homogeneous layer without field bookkeeping (keep_coupling=False): every operator of rcwa.py:1206-1222 and 1244-1281
@@ -455,7 +474,10 @@ class BatchedRCWA:
     def solve_global_smatrix(self):                                                     # rcwa.py:173-211
         n, B = self.n, self.B
         self._zero_layer_S = False
-        if self.layer_N > 0:
+        folded = self.fold_layers and self._running is not None
+        if folded:
+            S, C = self._running, [[], []]
+        elif self.layer_N > 0:
             S = self._layer_S(0)
             C = self._layer_C(0)
         else:
@@ -464,7 +486,7 @@ class BatchedRCWA:
             S = [I, Z, Z.clone(), I.clone()]
             C = [[], []]
             self._zero_layer_S = not (self.has_in or self.has_out)     # reference stores 1-D zeros (rcwa.py:187-188)
-        for i in range(1, self.layer_N):
+        for i in range(1, 0 if folded else self.layer_N):
             S, C = self._star(S, self._layer_S(i), C, self._layer_C(i))
         if self.has_in:                                                                 # rcwa.py:198-202
             S, C = self._star(self._Sin, S, [[], []], C)

@@ -11,18 +11,33 @@ namespace trx {
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+static int eig_vec_env() {
+    const char* e = getenv("TRX_EIG_VEC");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 0 && v <= 2) ? v : 0;
+}
+static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
+bool eig_uses_invit(int n) { return g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2; }
+int eig_set_knob(const char* key, int value) {
+    if (std::string(key) != "eig_vec" || value < 0 || value > 2) return TRX_ERR_ARG;
+    g_eig_vec = value;
+    return TRX_OK;
+}
+
+
 template <class T>
 size_t eig_ws_bytes_t(int n, int batch) {
     const size_t e = sizeof(cx<T>), B = batch, N = n;
     size_t tot = 0;
-    tot += al256(e * B * N * N) * 3;                                  // Z, X, Ht
-    tot += al256(B * N * N) + al256(sizeof(T) * B);                   // SW, hnorm
+    tot += al256(e * B * N * N) * 2;                                  // Z, X
+    if (eig_uses_invit(n)) tot += al256(e * B * N * N) + al256(B * N * N);     // Ht, SW: only the inverse-iteration route (knob eig_vec) needs them
+    tot += al256(sizeof(T) * B);                                      // hnorm
     tot += al256(e * B * N * EigPlan::HNB) * 2;                       // Vp, Yp
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Tp
     tot += al256(e * B * EigPlan::HNB * N) * 2;                       // W1, W2
     tot += al256(e * B * N * 2 * EigPlan::HNB) * 2;                   // YV, BC
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Sm
-    tot += al256(e * B * EigPlan::HNB);                               // tau
+    tot += al256(e * B * EigPlan::HNB) * 2;                           // tau, tvec
     tot += al256(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);   // U
     tot += al256(e * B * EigPlan::QKC * EigPlan::QNS);                // shifts
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
@@ -39,8 +54,8 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.A = (cx<T>*)A;
     Bf.Z = (cx<T>*)take(e * B * N * N);
     Bf.X = (cx<T>*)take(e * B * N * N);
-    Bf.Ht = (cx<T>*)take(e * B * N * N);
-    Bf.SW = (unsigned char*)take(B * N * N);
+    Bf.Ht = nullptr; Bf.SW = nullptr;
+    if (eig_uses_invit(n)) { Bf.Ht = (cx<T>*)take(e * B * N * N); Bf.SW = (unsigned char*)take(B * N * N); }
     Bf.hnorm = (T*)take(sizeof(T) * B);
     Bf.Vp = (cx<T>*)take(e * B * N * EigPlan::HNB);
     Bf.Yp = (cx<T>*)take(e * B * N * EigPlan::HNB);
@@ -51,6 +66,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.BC = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
     Bf.Sm = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
+    Bf.tvec = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.U = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QNS);
     Bf.bal_d = (T*)take(sizeof(T) * B * N);
@@ -58,18 +74,6 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
     Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
-}
-
-static int eig_vec_env() {
-    const char* e = getenv("TRX_EIG_VEC");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 0 && v <= 2) ? v : 0;
-}
-static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
-int eig_set_knob(const char* key, int value) {
-    if (std::string(key) != "eig_vec" || value < 0 || value > 2) return TRX_ERR_ARG;
-    g_eig_vec = value;
-    return TRX_OK;
 }
 
 namespace {
@@ -96,7 +100,7 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     // Automatic = Schur vectors: measured on MI355X (round 3, profiles/r03_invit_route.txt) the eigenvalues-only QR phase is 0.5 s shorter
     // per 128-matrix batch at n = 1922, but the solve kernel (a latency-bound recurrence of n barrier-separated steps per eigenvalue
     // group, 7 TF-equivalent of fp64 vector work) takes 1.05 s, and the route loses at every batch size from 1 to 128.
-    const bool invit = g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2;
+    const bool invit = eig_uses_invit(n);
     if (invit) {
         rc = invit_prepare<T>(s, B, n, batch);
         if (rc) return rc;

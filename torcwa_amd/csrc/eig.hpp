@@ -47,6 +47,7 @@ struct EigBuffers {
     cx<T>* BC;     // [B,2*HNB,n]   [Vt^H ; T^H W]
     cx<T>* Sm;     // [B,HNB,HNB]   V^H Y
     cx<T>* tau;    // [B,HNB]
+    cx<T>* tvec;   // [B,HNB]  V^H v of the current panel column
     cx<T>* U;      // [B,QKC,QW,QW] window unitary of each chain
     cx<T>* shifts; // [B,QKC,QNS]
     T* bal_d;      // [B,n] balancing scale D (A_balanced = D^-1 A D)

@@ -19,109 +19,75 @@ constexpr int HNB = EigPlan::HNB;   // panel width
 constexpr int HCT = 512;            // threads of the reflector kernel (one workgroup per matrix; 1024 measured no faster)
 constexpr int HRG = HCT / HNB;      // row groups of its HNB x HRG thread grid
 
+// ---- panel column c (matrix column j = p0 + c), fused formulation --------------------------------------------------------------------
+// zlahr2 per column:  b = a_j - Y conj(V[j,:]);  b -= V T^H (V^H b);  reflector v of b[j+1:];  y = tau (A v - Y (V^H v));  T[:,c] = -tau T (V^H v).
+// The straightforward mapping (one workgroup per matrix doing all of it around the wide A v launch) cost seven passes over the rows and four
+// block reductions per column: 100 us per column at n = 1922 and 166 us at n = 5202, all of it single-workgroup latency (a fifth of the
+// Hessenberg phase at batch 128, 18 % of a single large matrix's whole solve).  Here everything that is local to a row rides on the wide
+// launch, which streams the rows anyway:
+//   hess_gemv_kernel(c)  rows r of its block:  Yraw = A[r, j+1:] v;   Y[r,c] = tau_c (Yraw - Y[r,0:c] t_c)            (t_c = V^H v, from the column kernel)
+//                        and for the NEXT column:  b[r] = A[r, j+1] - Y[r,0:c+1] conj(V[j+1,0:c+1]) -> Bcol;   partial sums of V^H b -> wpart
+//   hess_col_kernel(c)   one workgroup per matrix:  w = T^H (sum of the partials);  b = Bcol - V w  (one pass, b kept in LDS);  one combined
+//                        reduction for |b[j+2:]|^2 and u = V[j+2:,:]^H b;  reflector;  write-back pass;  t_c = conj(V[j+1,:]) + scale u;  T[:,c].
 template <class T>
-__global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int ib, int c,
-                                                        cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall,
-                                                        cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all) {
+__global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int c, int nwg,
+                                                        cx<T>* __restrict__ Vall, cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all,
+                                                        cx<T>* __restrict__ tvec_all, const cx<T>* __restrict__ Bcol_all, const cx<T>* __restrict__ wpart_all) {
     TRX_DYN_SMEM(smem);
     cx<T>* bcol = reinterpret_cast<cx<T>*>(smem);     // [n]   current column (rows p0+1..n-1 at index r-(p0+1))
     cx<T>* part = bcol + n;                            // [HRG][HNB] partial sums
-    cx<T>* vec = part + HRG * HNB;                     // [HNB]  t / w vectors
+    cx<T>* vec = part + HRG * HNB;                     // [HNB]  w, then u
     T* red = reinterpret_cast<T*>(vec + HNB);          // [16] scalar reduction scratch
     const int b = blockIdx.x;
     cx<T>* A = Aall + (long)b * n * n;
     cx<T>* V = Vall + (long)b * n * HNB;
-    cx<T>* Y = Yall + (long)b * n * HNB;
     cx<T>* Tm = Tall + (long)b * HNB * HNB;
     cx<T>* tau = tau_all + (long)b * HNB;
+    cx<T>* tvec = tvec_all + (long)b * HNB;
+    const cx<T>* Bcol = Bcol_all + (long)b * n;
+    const cx<T>* wpart = wpart_all + (long)b * nwg * HNB;
     const int t = threadIdx.x;
     const int cc = t & (HNB - 1), rg = t / HNB;        // HNB x HRG thread grid
-    const int r0 = p0 + 1;                             // first row of R
-    const int nr = n - r0;
-
-    // ---- part 1: finalise column cp = c-1 of Y and T -------------------------------------------------------
+    const int r0 = p0 + 1, nr = n - r0, j = p0 + c;
+    // 1. w = T^H (V^H b), the partial sums of V^H b come from the wide launch of the previous column
     if (c > 0) {
-        const int cp = c - 1, jp = p0 + cp;
-        const cx<T> tau_p = tau[cp];
-        // t[q] = sum_{r > jp} conj(V[r,q]) * V[r,cp],  q < cp
-        cx<T> acc(T(0), T(0));
-        if (cc < cp)
-            for (int r = jp + 1 + rg; r < n; r += HRG) cfma_conj(acc, V[(long)r * HNB + cc], V[(long)r * HNB + cp]);
-        part[rg * HNB + cc] = acc;
-        __syncthreads();
-        if (t < HNB) {
-            cx<T> s(T(0), T(0));
-            for (int g = 0; g < HRG; ++g) s += part[g * HNB + t];
-            vec[t] = (t < cp) ? s : cx<T>(T(0), T(0));
-        }
-        __syncthreads();
-        // Y[r,cp] = tau * (Yraw[r,cp] - sum_q Y[r,q] t[q]),  r in R
-        for (int r = r0 + t; r < n; r += blockDim.x) {
-            cx<T> y = Y[(long)r * HNB + cp];
-            for (int q = 0; q < cp; ++q) cfma(y, -Y[(long)r * HNB + q], vec[q]);
-            Y[(long)r * HNB + cp] = tau_p * y;
-        }
-        // T[0:cp, cp] = -tau * T[0:cp,0:cp] t ;  T[cp,cp] = tau ; below-diagonal entries stay zero
-        if (t < HNB) {
-            cx<T> s(T(0), T(0));
-            if (t < cp) {
-                for (int q = t; q < cp; ++q) cfma(s, Tm[t * HNB + q], vec[q]);
-                s = -(tau_p * s);
-            } else if (t == cp) {
-                s = tau_p;
-            }
-            Tm[t * HNB + cp] = s;
-        }
-        __syncthreads();
-    }
-    if (c >= ib) return;
-
-    // ---- part 2: update column j with the pending reflectors of this panel, then build its reflector -------
-    const int j = p0 + c;
-    for (int i = t; i < nr; i += blockDim.x) bcol[i] = A[(long)(r0 + i) * n + j];
-    __syncthreads();
-    if (c > 0) {
-        // b -= Y[R,0:c] conj(V[j,0:c])
-        for (int i = t; i < nr; i += blockDim.x) {
-            cx<T> v = bcol[i];
-            for (int q = 0; q < c; ++q) cfma(v, -Y[(long)(r0 + i) * HNB + q], conj(V[(long)j * HNB + q]));
-            bcol[i] = v;
-        }
-        __syncthreads();
-        // w = V[R,0:c]^H b
         cx<T> acc(T(0), T(0));
         if (cc < c)
-            for (int i = rg; i < nr; i += HRG) cfma_conj(acc, V[(long)(r0 + i) * HNB + cc], bcol[i]);
+            for (int g = rg; g < nwg; g += HRG) acc += wpart[(long)g * HNB + cc];
         part[rg * HNB + cc] = acc;
         __syncthreads();
         if (t < HNB) {
-            cx<T> s(T(0), T(0));
-            for (int g = 0; g < HRG; ++g) s += part[g * HNB + t];
-            part[t] = (t < c) ? s : cx<T>(T(0), T(0));       // reuse row 0 of part as w
+            cx<T> sraw(T(0), T(0));
+            for (int g = 0; g < HRG; ++g) sraw += part[g * HNB + t];
+            vec[t] = (t < c) ? sraw : cx<T>(T(0), T(0));
         }
         __syncthreads();
-        // w <- T^H w   (T upper triangular:  (T^H w)[q] = sum_{p<=q} conj(T[p,q]) w[p])
-        if (t < HNB) {
-            cx<T> s(T(0), T(0));
-            if (t < c)
-                for (int p = 0; p <= t; ++p) cfma_conj(s, Tm[p * HNB + t], part[p]);
-            vec[t] = s;
-        }
+        cx<T> wq(T(0), T(0));
+        if (t < c)
+            for (int p = 0; p <= t; ++p) cfma_conj(wq, Tm[p * HNB + t], vec[p]);      // (T^H w)[q] = sum_{p<=q} conj(T[p,q]) w[p]
         __syncthreads();
-        // b -= V[R,0:c] w
-        for (int i = t; i < nr; i += blockDim.x) {
-            cx<T> v = bcol[i];
-            for (int q = 0; q < c; ++q) cfma(v, -V[(long)(r0 + i) * HNB + q], vec[q]);
-            bcol[i] = v;
-        }
+        if (t < HNB) vec[t] = wq;
         __syncthreads();
     }
-    // reflector for x = b[rows j+1 .. n-1]  (LAPACK zlarfg: H = I - tau v v^H, H^H x = beta e1)
+    // 2. b = Bcol - V w (first column of a panel: the column of A itself), kept in LDS
+    for (int i = t; i < nr; i += blockDim.x) {
+        cx<T> v = (c > 0) ? Bcol[r0 + i] : A[(long)(r0 + i) * n + j];
+        for (int q = 0; q < c; ++q) cfma(v, -V[(long)(r0 + i) * HNB + q], vec[q]);
+        bcol[i] = v;
+    }
+    __syncthreads();
+    // 3. one reduction round:  |b[j+2:]|^2  and  u[q] = sum_{r >= j+2} conj(V[r,q]) b[r]
     const int x0 = j + 1 - r0;                         // index of alpha inside bcol
     T ss = T(0);
     for (int i = x0 + 1 + t; i < nr; i += blockDim.x) ss += norm2(bcol[i]);
     ss = wave_sum(ss);
     if ((t & 63) == 0) red[t >> 6] = ss;
+    {
+        cx<T> acc(T(0), T(0));
+        if (cc < c)
+            for (int i = x0 + 1 + rg; i < nr; i += HRG) cfma_conj(acc, V[(long)(r0 + i) * HNB + cc], bcol[i]);
+        part[rg * HNB + cc] = acc;
+    }
     __syncthreads();
     T xn2 = T(0);
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) xn2 += red[w];
@@ -138,9 +104,28 @@ __global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall,
         tau_c = cx<T>((beta - alpha.x) / beta, -alpha.y / beta);
         scale = crecip(cx<T>(alpha.x - beta, alpha.y));
     }
-    __syncthreads();
+    // t_c = V^H v = conj(V[j+1,:]) + scale u   (v = [0 .. 0, 1, scale b[j+2:]]);   T[0:c,c] = -tau T t_c,  T[c,c] = tau
+    if (t < HNB) {
+        cx<T> u(T(0), T(0));
+        for (int g = 0; g < HRG; ++g) u += part[g * HNB + t];
+        cx<T> tq(T(0), T(0));
+        if (t < c) tq = conj(V[(long)(j + 1) * HNB + t]) + scale * u;
+        vec[t] = tq;
+        tvec[t] = tq;
+    }
     if (t == 0) tau[c] = tau_c;
-    // write back: rows <= j keep the updated values, A[j+1,j] = beta, below = 0; V[:,c] = [0...0, 1, v]
+    __syncthreads();
+    if (t < HNB) {
+        cx<T> sT(T(0), T(0));
+        if (t < c) {
+            for (int q = t; q < c; ++q) cfma(sT, Tm[t * HNB + q], vec[q]);
+            sT = -(tau_c * sT);
+        } else if (t == c) {
+            sT = tau_c;
+        }
+        if (t <= c) Tm[t * HNB + c] = sT;
+    }
+    // 4. write back: rows <= j keep the updated values, A[j+1,j] = beta, below = 0; V[:,c] = [0...0, 1, v]
     for (int i = t; i < nr; i += blockDim.x) {
         const int r = r0 + i;
         cx<T> a, v;
@@ -153,14 +138,18 @@ __global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall,
     for (int r = t; r < r0; r += blockDim.x) V[(long)r * HNB + c] = cx<T>(T(0), T(0));
 }
 
-// Yraw[r, c] = sum_{q>j} A[r, q] * V[q, c]   for r in [r0, n)
-// RPW rows per wave and pass: the v element read from LDS serves all of them, and RPW row loads per lane are in flight (2: measured
-// 5.07 TB/s in situ at the bench shape; 4 doubles the bytes in flight per CU, which is what an 8 TB/s stream with ~1 us of latency asks for)
+// Wide launch of column c.  RPW rows per wave and pass: the v element read from LDS serves all of them, and RPW row loads per lane are in
+// flight (2: 5.07 TB/s in situ at the bench shape; 4: +0.7 % / +2.7 % of the whole step at batch 128 / 16).  The row-local tail (Y final,
+// next column's b, partial V^H b) handles two rows at a time on the two halves of the wave (lane & 31 = panel column q).
 template <class T, int RPW>
-__global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c,
-                                                         const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, int rows_per_block) {
+__global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c, int next,
+                                                         const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, const cx<T>* __restrict__ tau_all,
+                                                         const cx<T>* __restrict__ tvec_all, cx<T>* __restrict__ Bcol_all, cx<T>* __restrict__ wpart_all,
+                                                         int rows_per_block) {
     TRX_DYN_SMEM(smem);
+    static_assert(RPW % 2 == 0 && HNB == 32, "two rows per half-wave round");
     cx<T>* v = reinterpret_cast<cx<T>*>(smem);        // [n - j - 1]
+    cx<T>* wred = v + (n - j - 1);                     // [waves][HNB] partial V^H b of each wave
     const int b = blockIdx.y;
     const cx<T>* A = Aall + (long)b * n * n;
     const cx<T>* V = Vall + (long)b * n * HNB;
@@ -169,30 +158,65 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
     for (int i = threadIdx.x; i < len; i += blockDim.x) v[i] = V[(long)(j + 1 + i) * HNB + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int q = lane & 31, half = lane >> 5;
     const int rbeg = r0 + blockIdx.x * rows_per_block;
+    const cx<T> tau_c = tau_all[(long)b * HNB + c];
+    const cx<T> tq = (q < c) ? tvec_all[(long)b * HNB + q] : cx<T>(T(0), T(0));
+    const cx<T> vjn = (next && q <= c) ? conj(V[(long)(j + 1) * HNB + q]) : cx<T>(T(0), T(0));       // conj(V[j+1, q]); V[j+1, c] = 1
+    cx<T> wacc(T(0), T(0));                            // this lane's share of sum_r conj(V[r,q]) b[r]
     for (int rr = RPW * wid; rr < rows_per_block; rr += RPW * nw) {
         const int ra = rbeg + rr;
         if (ra >= n) break;
         const cx<T>* row[RPW];
         cx<T> acc[RPW];
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const bool ok = (rr + q < rows_per_block) && (ra + q < n);
-            row[q] = A + (long)(ok ? ra + q : ra) * n + j + 1;       // a missing row re-reads the first one (its sum is not stored)
-            acc[q] = cx<T>(T(0), T(0));
+        for (int k = 0; k < RPW; ++k) {
+            const bool ok = (rr + k < rows_per_block) && (ra + k < n);
+            row[k] = A + (long)(ok ? ra + k : ra) * n + j + 1;       // a missing row re-reads the first one (its sum is not stored)
+            acc[k] = cx<T>(T(0), T(0));
         }
         for (int i = lane; i < len; i += 64) {
             const cx<T> vi = v[i];
             cx<T> a[RPW];
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) a[q] = row[q][i];
+            for (int k = 0; k < RPW; ++k) a[k] = row[k][i];
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) cfma(acc[q], a[q], vi);
+            for (int k = 0; k < RPW; ++k) cfma(acc[k], a[k], vi);
         }
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            acc[q].x = wave_sum(acc[q].x); acc[q].y = wave_sum(acc[q].y);
-            if (lane == 0 && (rr + q < rows_per_block) && (ra + q < n)) Y[(long)(ra + q) * HNB + c] = acc[q];
+        for (int k = 0; k < RPW; ++k) { acc[k].x = wave_sum(acc[k].x); acc[k].y = wave_sum(acc[k].y); }
+        // row-local tail, rows (2 kp + half) of the pass
+#pragma unroll
+        for (int kp = 0; kp < RPW / 2; ++kp) {
+            const int k = 2 * kp + half;
+            const int r = ra + k;
+            const bool ok = (rr + k < rows_per_block) && (r < n);
+            const cx<T> yraw = half ? acc[2 * kp + 1] : acc[2 * kp];
+            const cx<T> yq = (ok && q < c) ? Y[(long)r * HNB + q] : cx<T>(T(0), T(0));
+            cx<T> corr = yq * tq;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { corr.x += __shfl_xor(corr.x, o); corr.y += __shfl_xor(corr.y, o); }       // within the half-wave
+            const cx<T> yfin = tau_c * (yraw - corr);
+            if (ok && q == 0) Y[(long)r * HNB + c] = yfin;
+            if (next) {
+                cx<T> term = (q < c ? yq : (q == c ? yfin : cx<T>(T(0), T(0)))) * vjn;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { term.x += __shfl_xor(term.x, o); term.y += __shfl_xor(term.y, o); }
+                const cx<T> bnew = ok ? A[(long)r * n + j + 1] - term : cx<T>(T(0), T(0));
+                if (ok && q == 0) Bcol_all[(long)b * n + r] = bnew;
+                if (ok && q <= c) cfma_conj(wacc, V[(long)r * HNB + q], bnew);
+            }
+        }
+    }
+    if (next) {
+        // the two halves of a wave, then the waves of the workgroup
+        wacc.x += __shfl_xor(wacc.x, 32); wacc.y += __shfl_xor(wacc.y, 32);
+        if (lane < HNB) wred[wid * HNB + lane] = wacc;
+        __syncthreads();
+        if (threadIdx.x < HNB) {
+            cx<T> sW(T(0), T(0));
+            for (int w = 0; w < nw; ++w) sW += wred[w * HNB + threadIdx.x];
+            wpart_all[((long)b * gridDim.x + blockIdx.x) * HNB + threadIdx.x] = sW;
         }
     }
 }
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ 
 }  // namespace
 
 static int hess_rpw() {
-    static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return x == 4 ? 4 : 2; }();
+    static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return x == 2 ? 2 : 4; }();      // measured: 4 rows per pass +0.7 % (batch 128) / +2.7 % (batch 16) of the step
     return v;
 }
 
@@ -237,33 +261,37 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     cx<T>*A = B.A, *Z = B.Z, *V = B.Vp, *Y = B.Yp, *Tm = B.Tp, *W = B.W1, *W2 = B.W2;
     TRX_LAUNCH((set_identity_batched<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, Z, n);
     const size_t sm_col = sizeof(cx<T>) * ((size_t)n + HRG * HNB + HNB) + sizeof(T) * 16;
-    if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sizeof(cx<T>) * (size_t)n) ||
-        set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sizeof(cx<T>) * (size_t)n))
+    const size_t sm_gemv = sizeof(cx<T>) * ((size_t)n + 8 * HNB);
+    if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sm_gemv) ||
+        set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv))
         return TRX_ERR_LAUNCH;
     const int rpw = hess_rpw();
+    cx<T>* Bcol = W;            // [B, n]        next column with the pending right update applied (the GEMM scratch is free during the column loop)
+    cx<T>* wpart = W2;          // [B, nwg, HNB] partial sums of V^H b, one row per workgroup of the wide launch
     for (int p0 = 0; p0 < n - 2; p0 += HNB) {
         const int ib = (n - 2 - p0 < HNB) ? (n - 2 - p0) : HNB;
         const int r0 = p0 + 1, nr = n - r0;
         if (hipMemsetAsync(Tm, 0, sizeof(cx<T>) * sT * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-        for (int c = 0; c <= ib; ++c) {
+        // 64 rows per 4-wave workgroup fill the chip when the batch supplies the workgroups (batch 128 at n = 1922: 3840); one or
+        // two large matrices do not (n = 5202, batch 1: 82 workgroups on 256 CUs, and 83 KB of LDS for v leaves room for one
+        // workgroup per CU): there 16 rows per 8-wave workgroup give 4x the workgroups and twice the waves per CU
+        const bool few = (long)cdiv_i(nr, 64) * batch < 256;
+        const int rpb = few ? 16 : 64, gthreads = few ? 512 : 256;
+        const int nwg = cdiv_i(nr, rpb);
+        for (int c = 0; c < ib; ++c) {
+            const int j = p0 + c;
             { ProfScope prof(PROF_HESS_COL, s, 0, 0);
-              TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, ib, c, V, Y, Tm, B.tau); }
-            if (c < ib) {
-                const int j = p0 + c;
-                // 64 rows per 4-wave workgroup fill the chip when the batch supplies the workgroups (batch 128 at n = 1922: 3840); one or
-                // two large matrices do not (n = 5202, batch 1: 82 workgroups on 256 CUs, and 83 KB of LDS for v leaves room for one
-                // workgroup per CU): there 16 rows per 8-wave workgroup give 4x the workgroups and twice the waves per CU
-                const bool few = (long)cdiv_i(nr, 64) * batch < 256;
-                const int rpb = few ? 16 : 64, gthreads = few ? 512 : 256;
-                // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
-                ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
-                if (rpw == 4 && !few)
-                    TRX_LAUNCH((hess_gemv_kernel<T, 4>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
-                               (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
-                else
-                    TRX_LAUNCH((hess_gemv_kernel<T, 2>), dim3(cdiv_i(nr, rpb), batch), dim3(gthreads), sizeof(cx<T>) * (size_t)(n - j - 1), s,
-                               (const cx<T>*)A, n, r0, j, c, (const cx<T>*)V, Y, rpb);
-            }
+              TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, c, nwg, V, Tm, B.tau, B.tvec, (const cx<T>*)Bcol, (const cx<T>*)wpart); }
+            const int next = (c + 1 < ib) ? 1 : 0;
+            const size_t smg = sizeof(cx<T>) * ((size_t)(n - j - 1) + (gthreads / 64) * HNB);
+            // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
+            ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
+            if (rpw == 4 && !few)
+                TRX_LAUNCH((hess_gemv_kernel<T, 4>), dim3(nwg, batch), dim3(gthreads), smg, s, (const cx<T>*)A, n, r0, j, c, next, (const cx<T>*)V, Y,
+                           (const cx<T>*)B.tau, (const cx<T>*)B.tvec, Bcol, wpart, rpb);
+            else
+                TRX_LAUNCH((hess_gemv_kernel<T, 2>), dim3(nwg, batch), dim3(gthreads), smg, s, (const cx<T>*)A, n, r0, j, c, next, (const cx<T>*)V, Y,
+                           (const cx<T>*)B.tau, (const cx<T>*)B.tvec, Bcol, wpart, rpb);
         }
         int rc;
         const int mt = n - p0 - ib;       // trailing columns

@@ -61,7 +61,7 @@ def rectangle_density(nx, ny, Lx, Ly, Wx, Wy, Cx, Cy, theta=0.0, edge_sharpness=
 def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtype, precision, engine, orders,
                  polarization, direction, port, check_info):
     """layers: list of (thickness, eps[, mu]); thickness scalar or [b]; eps/mu scalar, [b] or [b,nx,ny]."""
-    sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False)
+    sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False, fold_layers=True)
     if eps_in is not None:
         sim.add_input_layer(eps=eps_in)
     if eps_out is not None:
