@@ -25,6 +25,20 @@
                  : "memory", "m0")
 #define TRX_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #endif
+// the same with a compile-time constant expression (0 .. 15)
+#define TRX_WAIT_VMCNT_N(expr)                                                                     \
+    do {                                                                                           \
+        constexpr int n__ = (expr);                                                                \
+        static_assert(n__ >= 0 && n__ <= 15, "vmcnt immediate");                                   \
+        if constexpr (n__ == 0) TRX_WAIT_VMCNT(0); else if constexpr (n__ == 1) TRX_WAIT_VMCNT(1); \
+        else if constexpr (n__ == 2) TRX_WAIT_VMCNT(2); else if constexpr (n__ == 3) TRX_WAIT_VMCNT(3); \
+        else if constexpr (n__ == 4) TRX_WAIT_VMCNT(4); else if constexpr (n__ == 5) TRX_WAIT_VMCNT(5); \
+        else if constexpr (n__ == 6) TRX_WAIT_VMCNT(6); else if constexpr (n__ == 7) TRX_WAIT_VMCNT(7); \
+        else if constexpr (n__ == 8) TRX_WAIT_VMCNT(8); else if constexpr (n__ == 9) TRX_WAIT_VMCNT(9); \
+        else if constexpr (n__ == 10) TRX_WAIT_VMCNT(10); else if constexpr (n__ == 11) TRX_WAIT_VMCNT(11); \
+        else if constexpr (n__ == 12) TRX_WAIT_VMCNT(12); else if constexpr (n__ == 13) TRX_WAIT_VMCNT(13); \
+        else if constexpr (n__ == 14) TRX_WAIT_VMCNT(14); else TRX_WAIT_VMCNT(15);                  \
+    } while (0)
 
 #define TRX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel), grid, block, shmem, stream, __VA_ARGS__)
@@ -153,6 +167,7 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);
 int lu_set_knob(const char* key, int value);          // trx_tuning("lu_split", rows)
+int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_dma", 0 / 1)
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);

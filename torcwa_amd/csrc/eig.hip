@@ -194,6 +194,7 @@ extern "C" int trx_tuning(const char* key, int value) {
     int rc = trx::qr_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::lu_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
     return rc == TRX_OK ? rc : trx::invit_set_knob(key, value);
 }
 

@@ -175,6 +175,17 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
             row[k] = A + (long)(ok ? ra + k : ra) * n + j + 1;       // a missing row re-reads the first one (its sum is not stored)
             acc[k] = cx<T>(T(0), T(0));
         }
+        // inputs of the row-local tail, requested BEFORE the row stream so that they have landed when it ends (two rows per round, one per
+        // half-wave; lane & 31 = panel column q)
+        cx<T> yq_[RPW / 2], vq_[RPW / 2], an_[RPW / 2];
+#pragma unroll
+        for (int kp = 0; kp < RPW / 2; ++kp) {
+            const int k = 2 * kp + half, r = ra + k;
+            const bool ok = (rr + k < rows_per_block) && (r < n);
+            yq_[kp] = (ok && q < c) ? Y[(long)r * HNB + q] : cx<T>(T(0), T(0));
+            vq_[kp] = (ok && next && q <= c) ? V[(long)r * HNB + q] : cx<T>(T(0), T(0));
+            an_[kp] = (ok && next) ? A[(long)r * n + j + 1] : cx<T>(T(0), T(0));
+        }
         for (int i = lane; i < len; i += 64) {
             const cx<T> vi = v[i];
             cx<T> a[RPW];
@@ -185,14 +196,13 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) { acc[k].x = wave_sum(acc[k].x); acc[k].y = wave_sum(acc[k].y); }
-        // row-local tail, rows (2 kp + half) of the pass
 #pragma unroll
         for (int kp = 0; kp < RPW / 2; ++kp) {
             const int k = 2 * kp + half;
             const int r = ra + k;
             const bool ok = (rr + k < rows_per_block) && (r < n);
             const cx<T> yraw = half ? acc[2 * kp + 1] : acc[2 * kp];
-            const cx<T> yq = (ok && q < c) ? Y[(long)r * HNB + q] : cx<T>(T(0), T(0));
+            const cx<T> yq = yq_[kp];
             cx<T> corr = yq * tq;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { corr.x += __shfl_xor(corr.x, o); corr.y += __shfl_xor(corr.y, o); }       // within the half-wave
@@ -202,9 +212,9 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
                 cx<T> term = (q < c ? yq : (q == c ? yfin : cx<T>(T(0), T(0)))) * vjn;
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) { term.x += __shfl_xor(term.x, o); term.y += __shfl_xor(term.y, o); }
-                const cx<T> bnew = ok ? A[(long)r * n + j + 1] - term : cx<T>(T(0), T(0));
+                const cx<T> bnew = ok ? an_[kp] - term : cx<T>(T(0), T(0));
                 if (ok && q == 0) Bcol_all[(long)b * n + r] = bnew;
-                if (ok && q <= c) cfma_conj(wacc, V[(long)r * HNB + q], bnew);
+                if (ok && q <= c) cfma_conj(wacc, vq_[kp], bnew);
             }
         }
     }
@@ -249,9 +259,11 @@ __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ 
 
 }  // namespace
 
-static int hess_rpw() {
-    static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return x == 2 ? 2 : 4; }();      // measured: 4 rows per pass +0.7 % (batch 128) / +2.7 % (batch 16) of the step
-    return v;
+// rows per wave and pass of the wide launch (TRX_HESS_RPW = 2 / 4 forces one).  Measured with the fused row-local tail (whole step, round 3):
+// batch 128: 2 rows 29.47-29.73, 4 rows 29.22-29.45 layer-solves/s;  batch 16: 2 rows 13.37, 4 rows 13.64
+static int hess_rpw(int batch) {
+    static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return (x == 2 || x == 4) ? x : 0; }();
+    return v ? v : (batch >= 64 ? 2 : 4);
 }
 
 template <class T>
@@ -265,7 +277,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sm_gemv) ||
         set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv))
         return TRX_ERR_LAUNCH;
-    const int rpw = hess_rpw();
+    const int rpw = hess_rpw(batch);
     cx<T>* Bcol = W;            // [B, n]        next column with the pending right update applied (the GEMM scratch is free during the column loop)
     cx<T>* wpart = W2;          // [B, nwg, HNB] partial sums of V^H b, one row per workgroup of the wide launch
     for (int p0 = 0; p0 < n - 2; p0 += HNB) {
