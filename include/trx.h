@@ -88,8 +88,11 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   "slab_pipe"   2 = software-pipelined off-window kernel (TRX_SLAB_PIPE)            auto: off (measured slower)
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chain unitary
  *   Eigenvector route of trx_eig
- *   "eig_vec"     1 = Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR phase (TRX_EIG_VEC)
- *                       auto: Schur vectors (measured faster at every batch size); trx_eig_ws_bytes depends on this knob
+ *   "eig_vec"     1 = all-fp64 pipeline with Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR
+ *                       phase, 3 = mixed precision: fp32 eigendecomposition refined to fp64 by Newton steps (TRX_EIG_VEC)
+ *                       auto: mixed precision for complex128 input of n >= 256, else Schur vectors; trx_eig_ws_bytes depends on this knob
+ *   "eig_refine"  1-4   Newton steps of the mixed-precision route; 0 = default (2: the accuracy class of the all-fp64 pipeline; one step
+ *                       leaves an eigen-residual of ~5e-12 ||A||, which is what torcwa_amd asks for on behalf of complex64 problems)
  *   "invit_cfg"   0-6   layout of the inverse-iteration kernel (TRX_INVIT_CFG): 0/1 512 threads, register prefetch 2 deep; 2: 3 deep;
  *                       3: 1 deep; 4: 1024 threads; 5 / 6: 1024 / 512 threads with the direct-to-LDS column ring
  *   "invit_ring"  1-3 (register variants) or 3-4 (ring variants) columns of H resident in LDS;  "invit_wpl" 1, 2, 4, 8: minimum waves

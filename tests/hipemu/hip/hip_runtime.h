@@ -46,6 +46,7 @@ inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); 
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
     for (size_t i = 0; i < h; ++i) memmove((char*)d + i * dp, (const char*)s + i * sp, w);
     return 0;
@@ -285,6 +286,7 @@ inline int __all(int pred) {
     return 1;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 template <class T>
 inline T __builtin_amdgcn_readfirstlane(T v) { return __shfl(v, 0); }
 

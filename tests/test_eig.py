@@ -264,3 +264,52 @@ def test_eig_inverse_iteration_layouts(backend, knobs):
     finally:
         _set_knobs(be, eig_vec=0, **{k: 0 for k in knobs})
     check(A, w, V, info, 1e-12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("steps", [2, 1])
+def test_eig_mixed_precision_route(backend, steps):
+    """Knob eig_vec = 3: fp32 eigendecomposition refined to fp64 by Newton steps (large GEMMs + one LU; eig_refine.hip), the default route
+    for n >= 256.  Two steps reach the accuracy class of the all-fp64 pipeline (same 1e-13 residual gate); one step (what a complex64
+    problem gets) leaves ~1e-10.  Matrix 1 has a spread spectrum, matrix 2 exactly repeated eigenvalues (pairs: 2 x 2 blocks
+    diagonalised in closed form)."""
+    be = get_backend(backend)
+    n = 70 if backend == "emu" else 600
+    A = (RNG.standard_normal((3, n, n)) + 1j * RNG.standard_normal((3, n, n))).astype(np.complex128)
+    A[1] = 0.3 * A[1] + np.diag(np.linspace(-9, 9, n)).astype(np.complex128)
+    Q, _ = np.linalg.qr(RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)))
+    lam = np.repeat(3.0 * (RNG.standard_normal(n // 2) + 1j * RNG.standard_normal(n // 2)), 2)
+    A[2] = (Q * lam[None, :]) @ Q.conj().T                          # normal, every eigenvalue double
+    try:
+        _set_knobs(be, eig_vec=3, eig_refine=steps)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, eig_vec=0, eig_refine=0)
+    check(A[:2], w[:2], V[:2], info[:2], 1e-13 if steps == 2 else 3e-8)
+    res = np.abs(A[2] @ V[2] - V[2] * w[2][None, :]).max() / np.abs(A[2]).max()
+    assert info[2] == 0 and res < (1e-12 if steps == 2 else 1e-8)
+    assert np.linalg.cond(V[2]) < 1e6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_mixed_precision_fallback(backend):
+    """Coupled clusters: a triple eigenvalue is diagonalised exactly inside the refinement (small dense solver); a ten-fold one is beyond
+    it -- the matrix is flagged and the batch is redone by the all-fp64 pipeline.  Same result quality either way, no error."""
+    be = get_backend(backend)
+    n = 40 if backend == "emu" else 300
+    Q, _ = np.linalg.qr(RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)))
+    lam = 2.0 * (RNG.standard_normal(n) + 1j * RNG.standard_normal(n))
+    lam[5] = lam[17] = lam[29]
+    lam2 = lam.copy()
+    lam2[:10] = 1.5 - 0.5j
+    A = np.stack([(Q * lam[None, :]) @ Q.conj().T, RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)), (Q * lam2[None, :]) @ Q.conj().T]).astype(np.complex128)
+    for sl in (slice(0, 2), slice(2, 3)):            # [triple + random]: resolved in the refinement; [ten-fold]: falls back
+        try:
+            _set_knobs(be, eig_vec=3)
+            w, V, info = run_eig(be, A[sl])
+        finally:
+            _set_knobs(be, eig_vec=0)
+        for b in range(w.shape[0]):
+            assert info[b] == 0
+            assert np.abs(A[sl][b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A[sl][b]).max() < 1e-12
+        assert np.linalg.cond(V[0]) < 1e6

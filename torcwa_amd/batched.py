@@ -244,7 +244,8 @@ class BatchedRCWA:
                 # A = P Q (rcwa.py:1236): with homogeneous mu the block structure needs two N^3 products, not one (2N)^3
                 A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
                 del Einv
-                lam, W = eng.eig(A, destroy=True)                                       # torch_eig.py:14
+                # mixed-precision eigensolver: two Newton steps for a complex64 problem (1e-5 gate), three for complex128 (engine.eig)
+                lam, W = eng.eig(A, destroy=True, refine_steps=3 if self._dtype == torch.complex128 else 2)      # torch_eig.py:14
                 del A
             kz = torch.sqrt(lam)
             kz = torch.where(torch.imag(kz) < 0, -kz, kz)                               # rcwa.py:1241

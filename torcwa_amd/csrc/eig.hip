@@ -14,16 +14,37 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static int eig_vec_env() {
     const char* e = getenv("TRX_EIG_VEC");
     const int v = e ? atoi(e) : 0;
-    return (v >= 0 && v <= 2) ? v : 0;
+    return (v >= 0 && v <= 3) ? v : 0;
 }
 static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
 bool eig_uses_invit(int n) { return g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2; }
+// mixed-precision route (fp32 eigendecomposition + Newton refinement in fp64, eig_refine.hip): fp64 problems of at least 256 rows
+bool eig_uses_mixed(int n, size_t elem) { return elem == 8 && ((g_eig_vec == 3 && n >= 8) || (g_eig_vec == 0 && n >= 256)); }
 int eig_set_knob(const char* key, int value) {
-    if (std::string(key) != "eig_vec" || value < 0 || value > 2) return TRX_ERR_ARG;
+    if (std::string(key) != "eig_vec" || value < 0 || value > 3) return TRX_ERR_ARG;
     g_eig_vec = value;
     return TRX_OK;
 }
 
+
+template <class T> size_t eig_ws_bytes_t(int n, int batch);
+static size_t eig_ws_bytes_f32(int n, int batch) { return eig_ws_bytes_t<float>(n, batch); }
+
+// Mixed route, on top of the all-fp64 layout: Z doubles as the second eigenvector buffer and X as G; extra: M [B,n,n] + pivots / flags /
+// pairs + the fp32 pool (A32, V32, w32, the fp32 eigensolver's own workspace), which is dead before G and M are first written and
+// therefore overlaps them where it can (X and M are carved adjacent: pool = X | M | spill).
+static size_t mixed_pool_bytes(int n, int batch) {
+    const size_t B = batch, N = n;
+    return eig_ws_bytes_f32(n, batch) + 2 * al256(8 * B * N * N) + al256(8 * B * N);
+}
+static size_t mixed_extra_bytes(int n, int batch) {
+    const size_t B = batch, N = n, e = 16;
+    const size_t xm = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
+    size_t tot = al256(e * B * N * N);                                        // M
+    if (pool > xm) tot += al256(pool - xm);                                    // spill of the fp32 pool beyond X | M
+    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(REFINE_CLUSTER_BYTES * B);
+    return tot;
+}
 
 template <class T>
 size_t eig_ws_bytes_t(int n, int batch) {
@@ -43,6 +64,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
     tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
+    if (eig_uses_mixed(n, sizeof(T))) tot += mixed_extra_bytes(n, batch);
     return tot;
 }
 
@@ -54,6 +76,17 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.A = (cx<T>*)A;
     Bf.Z = (cx<T>*)take(e * B * N * N);
     Bf.X = (cx<T>*)take(e * B * N * N);
+    Bf.mixedM = nullptr;
+    Bf.mixed_pool = nullptr;
+    Bf.mixed_pool_bytes = 0;
+    if (eig_uses_mixed(n, sizeof(T))) {
+        // X | M | spill: the fp32 pool of the mixed route overlaps X (later G) and M, which are first written after it is dead
+        const size_t xm = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
+        Bf.mixedM = (cx<T>*)take(e * B * N * N);
+        if (pool > xm) (void)take(pool - xm);
+        Bf.mixed_pool = (char*)Bf.X;
+        Bf.mixed_pool_bytes = pool > xm ? pool : xm;
+    }
     Bf.Ht = nullptr; Bf.SW = nullptr;
     if (eig_uses_invit(n)) { Bf.Ht = (cx<T>*)take(e * B * N * N); Bf.SW = (unsigned char*)take(B * N * N); }
     Bf.hnorm = (T*)take(sizeof(T) * B);
@@ -74,9 +107,31 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
     Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
+    Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = nullptr;
+    Bf.r_eoff = Bf.r_lmax = nullptr;
+    Bf.r_pairX = nullptr;
+    if (eig_uses_mixed(n, sizeof(T))) {
+        Bf.r_piv = (int*)take(sizeof(int) * B * N);
+        Bf.r_partner = (int*)take(sizeof(int) * B * N);
+        Bf.r_linfo = (int*)take(sizeof(int) * (B + 1));
+        Bf.r_flags = (int*)take(sizeof(int) * (B + 1));
+        Bf.r_eoff = (T*)take(8 * B);
+        Bf.r_lmax = (T*)take(8 * B);
+        Bf.r_pairX = (cx<T>*)take(REFINE_CLUSTER_BYTES * B);
+    }
 }
 
 namespace {
+__global__ __launch_bounds__(256) void cvt_c128_c64_kernel(const cx<double>* __restrict__ in, cx<float>* __restrict__ out, long count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { const cx<double> v = in[i]; out[i] = cx<float>((float)v.x, (float)v.y); }
+}
+int eig_mixed_convert(hipStream_t s, const cx<double>* in, cx<float>* out, long count) {
+    TRX_LAUNCH(cvt_c128_c64_kernel, dim3(cdiv_i(count, 256)), dim3(256), 0, s, in, out, count);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void clear_below_subdiag_kernel(cx<T>* __restrict__ Aall, int n) {
     cx<T>* A = Aall + (long)blockIdx.z * n * n;
@@ -85,6 +140,10 @@ __global__ __launch_bounds__(256) void clear_below_subdiag_kernel(cx<T>* __restr
     if (j < n && i > j + 1) A[(long)i * n + j] = cx<T>(T(0), T(0));
 }
 
+// all-fp64 (or all-fp32) pipeline after the balancing
+template <class T>
+int eig_after_balance(hipStream_t s, const EigBuffers<T>& B, void* w, void* V, int n, int batch, int* info);
+
 template <class T>
 int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info, void* ws) {
     EigBuffers<T> B;
@@ -92,7 +151,38 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
     int rc = balance<T>(s, B, n, batch);          // A <- D^-1 A D (zgebal 'S'); undone on the eigenvectors in schur_vectors
     if (rc) return rc;
-    rc = hessenberg<T>(s, B, n, batch);
+    if constexpr (sizeof(T) == 8) {
+        if (eig_uses_mixed(n, sizeof(T))) {
+            // Mixed-precision route (eig_refine.hip): the balanced matrix stays intact in fp64; its fp32 copy goes through the fp32 pipeline
+            // (which balances once more: a no-op up to rounding) and the result is refined by Newton steps made of fp64 GEMMs and one LU.
+            const size_t Bn = batch, N = n;
+            char* p = B.mixed_pool;
+            cx<float>* A32 = (cx<float>*)p; p += al256(8 * Bn * N * N);
+            cx<float>* V32 = (cx<float>*)p; p += al256(8 * Bn * N * N);
+            cx<float>* w32 = (cx<float>*)p; p += al256(8 * Bn * N);
+            void* ws32 = p;
+            rc = eig_mixed_convert(s, (const cx<double>*)A, A32, (long)Bn * N * N);
+            if (rc) return rc;
+            rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32);      // (its info is folded into the flags below)
+            if (rc) return rc;
+            RefineBuffers<T> R;
+            R.G = B.X; R.M = B.mixedM; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;
+            R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
+            int any = 0;
+            // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
+            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, refine_steps(), &any);
+            if (rc) return rc;
+            if (!any) return finish_vectors<T>(s, B, n, batch, (cx<T>*)V);
+            // some matrix has a cluster of more than two eigenvalues, an fp32 result that is too far off, or a singular V: redo the batch
+            // in fp64 (A is still the balanced input, the scaling D is kept)
+        }
+    }
+    return eig_after_balance<T>(s, B, w, V, n, batch, info);
+}
+
+template <class T>
+int eig_after_balance(hipStream_t s, const EigBuffers<T>& B, void* w, void* V, int n, int batch, int* info) {
+    int rc = hessenberg<T>(s, B, n, batch);
     if (rc) return rc;
     TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
     // Eigenvector route (knob eig_vec: 0 = automatic, 1 = Schur vectors, 2 = inverse iteration).  Inverse iteration (eig_invit.hip): the
@@ -195,6 +285,7 @@ extern "C" int trx_tuning(const char* key, int value) {
     if (rc != TRX_OK) rc = trx::lu_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::refine_set_knob(key, value);
     return rc == TRX_OK ? rc : trx::invit_set_knob(key, value);
 }
 

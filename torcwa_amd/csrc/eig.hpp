@@ -55,7 +55,35 @@ struct EigBuffers {
     int* bal_flags; // [B] per-matrix "needs balancing" flags (sized for 2B)
     QrState* st;   // [B]
     int* summary;  // [64]: 8 ints per iteration group of the QR phase (up to 8 groups)
+    // mixed-precision route (fp64 only; null otherwise)
+    cx<T>* mixedM;             // [B,n,n] directly behind X
+    char* mixed_pool;          // fp32 pool = X | M | spill
+    size_t mixed_pool_bytes;
+    int *r_piv, *r_linfo, *r_flags, *r_partner;
+    T *r_eoff, *r_lmax;
+    cx<T>* r_pairX;
 };
+
+// buffers of the mixed-precision route (eig_refine.hip): fp32 eigendecomposition + Newton refinement in fp64
+template <class T>
+struct RefineBuffers {
+    cx<T>* G;        // [B,n,n]  A V, then V^-1 A V
+    cx<T>* M;        // [B,n,n]  (I + F) R
+    cx<T>* V1;       // [B,n,n]  second eigenvector buffer (LU copy, then the next iterate)
+    int* piv;        // [B,n]
+    int* linfo;      // [B]
+    int* flags;      // [B + 1]  per matrix: 1 = off-diagonal part not small, 2 = a cluster the exact treatment does not take; [B] = any flag or LU failure
+    T* eoff;         // [B] max off-diagonal |G_ij|
+    T* lmax;         // [B] max |G_ii|
+    int* partner;    // [B,n]
+    cx<T>* pairX;    // [B] cluster tables (RefineClusters<T>, REFINE_CLUSTER_BYTES each)
+    int* clus;       // [B,n]  256 * cluster + position, or -1 (aliases piv: the pivots are dead once the step's solve is done)
+};
+constexpr size_t REFINE_CLUSTER_BYTES = 280 * 1024;
+template <class T> int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const cx<float>* V32, const cx<float>* w32, cx<T>* w, cx<T>* V,
+                                  int n, int batch, int steps, int* host_any);
+int refine_set_knob(const char* key, int value);
+int refine_steps();
 
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, int batch);

@@ -1,0 +1,419 @@
+// Mixed-precision route of trx_eig (fp64 problems, n >= 256: the default): the eigendecomposition is computed in fp32 by the same
+// pipeline (balancing -> Hessenberg -> multi-shift QR -> Schur vectors: half the bytes, twice the matrix-core rate, 1.9 s instead of 3.3 s
+// per 128-matrix batch at n = 1922) and then REFINED to fp64 accuracy by Newton steps on the eigendecomposition, which are nothing but
+// large fp64 GEMMs and one LU -- the shapes the chip is good at (0.49 s per step):
+//
+//     G = V^-1 A V            (A V, LU of V, one n-column solve)       = Lambda + E,  E small when (Lambda, V) is nearly right
+//     lambda_i <- G_ii;    F_ij = E_ij / (lambda_j - lambda_i)  (i != j);    V <- V (I + F)       [first-order perturbation theory]
+//
+// The step is quadratically convergent as long as |E_ij| << |lambda_j - lambda_i|.  A pair whose coupling is not small against its gap
+// (|G_ij| + |G_ji| > 0.1 |lambda_j - lambda_i|; equal eigenvalues included) is COUPLED: the individual vectors are ill determined there and
+// the formula is not applied.  The connected components of the coupling graph (the degenerate mode pairs of symmetric meta-atoms; at
+// n = 1922 up to ~150 indices in pairs and the odd triple left by the fp32 start) are diagonalised exactly from their blocks of G by a small
+// dense solver; a component of more than 8 indices, more than 1024 coupled indices, a defective block, an off-diagonal part that is not
+// small, or a failed LU flag the matrix, and trx_eig then redoes the batch with the all-fp64 pipeline (the balanced input is kept
+// intact for that).
+// Measured (MI355X, bench operator, n = 1922): the fp32 start leaves max |E| = 2e-2 ... 2e-1 (|lambda| up to 2.6e3); after one step 2.4e-4,
+// which is NOT yet inside the 1e-5 gate of a complex64 problem for every S-parameter; after two steps the complex64 and complex128 parity
+// tests pass (1e-5 / 1e-9 against the reference fixtures).  Steps: knob eig_refine (library default 2; torcwa_amd asks for 3 on behalf of
+// complex128 problems and of the differentiable path).  numpy statement of the method: the eigen-residual of LAPACK-fp32 eigenpairs of
+// the same operator falls from 5e-8 ||A|| to 4e-11 and 6e-15 in two steps (LAPACK zgeev itself: 2e-14).
+#include "eig.hpp"
+#include <cstdlib>
+#include <limits>
+#include <string>
+#include <vector>
+#include "prof.hpp"
+
+namespace trx {
+namespace {
+
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void cvt_kernel(const cx<TI>* __restrict__ in, cx<TO>* __restrict__ out, long count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { const cx<TI> v = in[i]; out[i] = cx<TO>((TO)v.x, (TO)v.y); }
+}
+
+// eoff[b] = max off-diagonal |G_ij| (abs1), lmax[b] = max |G_ii|;  lam[b, i] = G_ii
+template <class T>
+__global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, T* __restrict__ eoff, T* __restrict__ lmax) {
+    __shared__ T red[2][4];
+    const int b = blockIdx.x;
+    const cx<T>* G = Gall + (long)b * n * n;
+    T eo = T(0), lm = T(0);
+    for (long e = threadIdx.x; e < (long)n * n; e += blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e - (long)i * n);
+        const T a = abs1(G[e]);
+        if (i == j) { lam[(long)b * n + i] = G[e]; lm = a > lm ? a : lm; }
+        else eo = (a > eo || !(a == a)) ? a : eo;                      // a NaN sticks
+    }
+    eo = wave_max(eo); lm = wave_max(lm);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = eo; red[1][threadIdx.x >> 6] = lm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { eo = (red[0][w] > eo || !(red[0][w] == red[0][w])) ? red[0][w] : eo; lm = red[1][w] > lm ? red[1][w] : lm; }
+        eoff[b] = eo; lmax[b] = lm;
+    }
+}
+
+// Which pairs (i, j) can NOT take the first-order formula: those whose coupling is not small against their gap,
+//     |G_ij| + |G_ji| > rho |lambda_j - lambda_i|      (rho = 0.1; equal eigenvalues included).
+// A global distance threshold would lump together every pair of close eigenvalues -- at n = 1922 the fp32 start leaves max |E| = 4e-4 and
+// the spectrum has gaps of 2e-3 -- although close eigenvalues are, as a rule, hardly coupled at all: with this criterion the bench operator
+// has NO coupled pair (numpy statement at order [15,15]: residual 4e-11 after one step, 6e-15 after two), a square meta-atom exactly its
+// degenerate pairs.  partner[b, i]: -1 = uncoupled, j >= 0 = coupled to exactly one index (a pair), -2 = to several (flags the matrix).
+template <class T>
+__global__ __launch_bounds__(256) void refine_cluster_kernel(const cx<T>* __restrict__ Gall, const cx<T>* __restrict__ lam, int n, const T* __restrict__ eoff,
+                                                             const T* __restrict__ lmax, int* __restrict__ partner, int* __restrict__ flags) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cx<T>* G = Gall + (long)b * n * n;
+    const cx<T>* l = lam + (long)b * n;
+    const T eo = eoff[b], lm = lmax[b];
+    if (!(eo <= T(1e-2) * lm)) { if (i == 0) atomicOr(&flags[b], 1); }       // the fp32 result is not close enough (or not finite)
+    const T rho = T(0.1);
+    const cx<T> li = l[i];
+    int cnt = 0, pj = -1;
+    for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const T c = abs1(G[(long)i * n + j]) + abs1(G[(long)j * n + i]);
+        if (!(c <= rho * abs1(l[j] - li))) { ++cnt; pj = j; }
+    }
+    partner[(long)b * n + i] = cnt == 0 ? -1 : pj;       // >= 0: coupled to at least one other index
+    (void)pj;
+}
+
+// ---- exact treatment of the (few, small) coupled clusters ------------------------------------------------------------------------------
+constexpr int RCM = 8;        // largest cluster diagonalised here
+constexpr int RCL = 1024;     // most coupled indices per matrix
+constexpr int RCK = 256;      // most clusters per matrix
+template <class T>
+struct RefineClusters {       // per matrix (at most REFINE_CLUSTER_BYTES)
+    int ncl, pad;
+    int size[RCK];
+    int member[RCK][RCM];
+    cx<T> X[RCK][RCM * RCM];  // columns = eigenvectors of the cluster's block of G, in the basis of its members
+};
+
+static_assert(sizeof(RefineClusters<double>) <= REFINE_CLUSTER_BYTES, "cluster table");
+
+// Schur form + eigenvectors of a dense m x m block (m <= RCM), serial: Hessenberg by Givens rotations, explicitly shifted QR
+// iterations with deflation, triangular back-substitution, X = Z Y with unit columns.  Returns false if it did not converge or the
+// eigenvector matrix is numerically singular (a defective block): the caller then leaves the cluster alone and flags the matrix.
+template <class T>
+__device__ bool small_dense_eig(cx<T>* Bm, int m, cx<T>* Z, cx<T>* mu, cx<T>* X) {
+    auto at = [&](cx<T>* M_, int r, int c) -> cx<T>& { return M_[r * RCM + c]; };
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < m; ++c) at(Z, r, c) = cx<T>(r == c ? T(1) : T(0), T(0));
+    // rotation G = [[c, s], [-conj(s), c]] with G [f; g] = [r; 0]
+    auto rotg = [&](cx<T> f, cx<T> g, T& c, cx<T>& sn) {
+        const T ag = cabs(g);
+        if (ag == T(0)) { c = T(1); sn = cx<T>(T(0), T(0)); return; }
+        const T af = cabs(f);
+        if (af == T(0)) { c = T(0); sn = (T(1) / ag) * conj(g); return; }
+        const T d = sqrt(af * af + ag * ag);
+        c = af / d;
+        sn = (T(1) / (af * d)) * (f * conj(g));
+    };
+    auto rot_rows = [&](int r1, int r2, T c, cx<T> sn, int c0) {       // rows r1, r2 of Bm <- G rows
+        for (int q = c0; q < m; ++q) {
+            const cx<T> x = at(Bm, r1, q), y = at(Bm, r2, q);
+            at(Bm, r1, q) = c * x + sn * y;
+            at(Bm, r2, q) = c * y - conj(sn) * x;
+        }
+    };
+    auto rot_cols = [&](cx<T>* M_, int c1, int c2, T c, cx<T> sn, int rmax) {   // columns <- columns G^H
+        for (int r = 0; r < rmax; ++r) {
+            const cx<T> x = at(M_, r, c1), y = at(M_, r, c2);
+            at(M_, r, c1) = c * x + conj(sn) * y;
+            at(M_, r, c2) = c * y - sn * x;
+        }
+    };
+    // Hessenberg form: zero column c below the subdiagonal with rotations in the planes (r-1, r)
+    for (int c = 0; c + 2 < m; ++c)
+        for (int r = m - 1; r >= c + 2; --r) {
+            T cs; cx<T> sn;
+            rotg(at(Bm, r - 1, c), at(Bm, r, c), cs, sn);
+            rot_rows(r - 1, r, cs, sn, c);
+            at(Bm, r, c) = cx<T>(T(0), T(0));
+            rot_cols(Bm, r - 1, r, cs, sn, m);
+            rot_cols(Z, r - 1, r, cs, sn, m);
+        }
+    // shifted QR iterations on the active block [l, hi]
+    const T ulp = eps_of<T>::value;
+    int hi = m - 1, its = 0, total = 0;
+    while (hi > 0) {
+        int l = hi;
+        while (l > 0) {
+            T sc = abs1(at(Bm, l - 1, l - 1)) + abs1(at(Bm, l, l));
+            if (sc == T(0)) sc = T(1);
+            if (abs1(at(Bm, l, l - 1)) <= ulp * sc) { at(Bm, l, l - 1) = cx<T>(T(0), T(0)); break; }
+            --l;
+        }
+        if (l == hi) { --hi; its = 0; continue; }
+        if (++total > 60 * m) return false;
+        ++its;
+        cx<T> sig;
+        {
+            const cx<T> a = at(Bm, hi - 1, hi - 1), bq = at(Bm, hi - 1, hi), cq = at(Bm, hi, hi - 1), d = at(Bm, hi, hi);
+            if (its % 10 == 0) sig = d + cx<T>(T(0.75) * abs1(cq), T(0));
+            else {
+                const cx<T> tr = T(0.5) * (a + d);
+                const cx<T> sq = csqrt((a - tr) * (d - tr) * T(-1) + bq * cq);
+                const cx<T> e1 = tr + sq, e2 = tr - sq;
+                sig = (abs1(e1 - d) < abs1(e2 - d)) ? e1 : e2;
+            }
+        }
+        // implicit single-shift sweep (bulge chase with rotations)
+        cx<T> f = at(Bm, l, l) - sig, g = at(Bm, l + 1, l);
+        for (int r = l; r < hi; ++r) {
+            T cs; cx<T> sn;
+            if (r > l) { f = at(Bm, r, r - 1); g = at(Bm, r + 1, r - 1); }
+            rotg(f, g, cs, sn);
+            rot_rows(r, r + 1, cs, sn, r > l ? r - 1 : l);
+            if (r > l) at(Bm, r + 1, r - 1) = cx<T>(T(0), T(0));
+            rot_cols(Bm, r, r + 1, cs, sn, (r + 2 < m ? r + 2 : m - 1) + 1);
+            rot_cols(Z, r, r + 1, cs, sn, m);
+        }
+    }
+    // eigenvectors of the triangular factor, X = Z Y
+    T tn = T(0);
+    for (int r = 0; r < m; ++r)
+        for (int c = r; c < m; ++c) { const T a = abs1(at(Bm, r, c)); tn = a > tn ? a : tn; }
+    const T smin = (tn > T(0) ? tn : T(1)) * ulp;
+    for (int k = 0; k < m; ++k) {
+        cx<T> y[RCM];
+        const cx<T> lam = at(Bm, k, k);
+        mu[k] = lam;
+        for (int r = 0; r < m; ++r) y[r] = cx<T>(T(0), T(0));
+        y[k] = cx<T>(T(1), T(0));
+        for (int r = k - 1; r >= 0; --r) {
+            cx<T> sacc(T(0), T(0));
+            for (int q = r + 1; q <= k; ++q) cfma(sacc, at(Bm, r, q), y[q]);
+            cx<T> d = at(Bm, r, r) - lam;
+            if (abs1(d) < smin) d = cx<T>(smin, T(0));
+            y[r] = cdiv(-sacc, d);
+        }
+        T nrm = T(0);
+        for (int r = 0; r < m; ++r) {
+            cx<T> v(T(0), T(0));
+            for (int q = 0; q <= k; ++q) cfma(v, at(Z, r, q), y[q]);
+            at(X, r, k) = v;
+            nrm += norm2(v);
+        }
+        const T inv = nrm > T(0) ? T(1) / sqrt(nrm) : T(1);
+        for (int r = 0; r < m; ++r) at(X, r, k) = inv * at(X, r, k);
+    }
+    // conditioning guard: |det X| of unit-column X by elimination on a copy (Z is free now)
+    for (int e = 0; e < m * RCM; ++e) Z[e] = X[e];
+    T ldet = T(1);
+    for (int c = 0; c < m; ++c) {
+        int pr = c; T best = abs1(at(Z, c, c));
+        for (int r = c + 1; r < m; ++r) { const T a = abs1(at(Z, r, c)); if (a > best) { best = a; pr = r; } }
+        if (!(best > T(0))) return false;
+        if (pr != c) for (int q = 0; q < m; ++q) { const cx<T> tmp = at(Z, c, q); at(Z, c, q) = at(Z, pr, q); at(Z, pr, q) = tmp; }
+        ldet *= cabs(at(Z, c, c));
+        for (int r = c + 1; r < m; ++r) {
+            const cx<T> fct = cdiv(at(Z, r, c), at(Z, c, c));
+            for (int q = c; q < m; ++q) cfma(at(Z, r, q), -fct, at(Z, c, q));
+        }
+    }
+    return ldet >= T(1e-6);
+}
+
+// One 64-thread workgroup per matrix: connected components of the coupling graph among the coupled indices (a few to a few hundred of the
+// n at the bench shape, nearly all of them isolated pairs), exact diagonalisation of every component's block of G (one thread per
+// component), cluster tables for the build kernel.  clus[b, i] = 256 * cluster + position, or -1.
+constexpr int RCE = 4096;     // most coupled pairs (edges) per matrix
+template <class T>
+__global__ __launch_bounds__(64) void refine_solve_clusters_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, const int* __restrict__ partner,
+                                                                    int* __restrict__ clus, RefineClusters<T>* __restrict__ tab, int* __restrict__ flags) {
+    __shared__ int list[RCL], lab[RCL], cid[RCL], ep[RCE], eq[RCE];
+    __shared__ int nl_s, ne_s, changed_s, bad_s;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const cx<T>* G = Gall + (long)b * n * n;
+    const int* pt = partner + (long)b * n;
+    int* cl = clus + (long)b * n;
+    RefineClusters<T>& Tb = tab[b];
+    if (t == 0) { nl_s = 0; ne_s = 0; bad_s = 0; Tb.ncl = 0; }
+    __syncthreads();
+    // 1. the coupled indices, in ascending order (ballot prefix per chunk of 64)
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + t;
+        const bool c = i < n && pt[i] >= 0;
+        if (i < n) cl[i] = -1;
+        const unsigned long long m = __ballot(c);
+        const int base = nl_s;
+        if (c) {
+            const int pos = base + __popcll(m & ((1ull << t) - 1ull));
+            if (pos < RCL) { list[pos] = i; lab[pos] = pos; }
+        }
+        __syncthreads();
+        if (t == 0) nl_s = base + __popcll(m);
+        __syncthreads();
+    }
+    const int nl = nl_s;
+    if (nl == 0) return;
+    if (nl > RCL) { if (t == 0) atomicOr(&flags[b], 2 | 32); return; }
+    // 2. the coupled pairs among them
+    const T rho = T(0.1);
+    for (int p = t; p < nl; p += 64) {
+        const int i = list[p];
+        const cx<T> gii = G[(long)i * n + i];
+        for (int q = p + 1; q < nl; ++q) {
+            const int j = list[q];
+            const T c = abs1(G[(long)i * n + j]) + abs1(G[(long)j * n + i]);
+            if (!(c <= rho * abs1(G[(long)j * n + j] - gii))) {
+                const int e = atomicAdd(&ne_s, 1);
+                if (e < RCE) { ep[e] = p; eq[e] = q; }
+            }
+        }
+    }
+    __syncthreads();
+    const int ne = ne_s;
+    if (ne > RCE) { if (t == 0) atomicOr(&flags[b], 2 | 32); return; }
+    // 3. components: label propagation over the edges
+    for (int sweep = 0; sweep < RCL; ++sweep) {
+        if (t == 0) changed_s = 0;
+        __syncthreads();
+        for (int e = t; e < ne; e += 64) {
+            const int lp = lab[ep[e]], lq = lab[eq[e]];
+            if (lp < lq) { atomicMin(&lab[eq[e]], lp); changed_s = 1; }
+            else if (lq < lp) { atomicMin(&lab[ep[e]], lq); changed_s = 1; }
+        }
+        __syncthreads();
+        const int ch = changed_s;
+        __syncthreads();
+        if (!ch) break;
+    }
+    // 4. cluster numbering and member lists (serial: a few hundred entries)
+    if (t == 0) {
+        int ncl = 0;
+        for (int p = 0; p < nl && !bad_s; ++p) {
+            if (lab[p] == p) {
+                if (ncl == RCK) { bad_s = 128; break; }
+                cid[p] = ncl; Tb.size[ncl] = 0; ++ncl;
+            }
+            const int c = cid[lab[p]];              // the representative has the smallest position: numbered before its members
+            if (Tb.size[c] == RCM) { bad_s = 64; break; }
+            Tb.member[c][Tb.size[c]++] = list[p];
+        }
+        Tb.ncl = ncl;
+        for (int c = 0; c < ncl && !bad_s; ++c) if (Tb.size[c] < 2) bad_s = 128;
+    }
+    __syncthreads();
+    if (bad_s) { if (t == 0) atomicOr(&flags[b], 2 | bad_s); return; }
+    // 5. every cluster: exact eigendecomposition of its block of G
+    const int ncl = Tb.ncl;
+    for (int c = t; c < ncl; c += 64) {
+        cx<T> Bm[RCM * RCM], Z[RCM * RCM], mu[RCM];
+        const int m = Tb.size[c];
+        for (int r = 0; r < m; ++r)
+            for (int q = 0; q < m; ++q) Bm[r * RCM + q] = G[(long)Tb.member[c][r] * n + Tb.member[c][q]];
+        if (!small_dense_eig<T>(Bm, m, Z, mu, Tb.X[c])) { atomicOr(&flags[b], 2 | 256); continue; }
+        for (int r = 0; r < m; ++r) { const int i = Tb.member[c][r]; cl[i] = 256 * c + r; lam[(long)b * n + i] = mu[r]; }
+    }
+}
+
+// M = (I + F) R:  F_kj = G_kj / (lamd_j - lamd_k) outside the clusters (lamd = diag G), R = the eigenvector matrices of the clusters applied to their columns
+template <class T>
+__global__ __launch_bounds__(256) void refine_build_kernel(const cx<T>* __restrict__ Gall, int n, const int* __restrict__ clus, const RefineClusters<T>* __restrict__ tab,
+                                                           cx<T>* __restrict__ Mall) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const cx<T>* G = Gall + (long)b * n * n;
+    const int* cl = clus + (long)b * n;
+    const int ck = cl[k], cj = cl[j];
+    auto entry = [&](int col, int ccol) {                               // (I + F)[k, col]
+        if (k == col) return cx<T>(T(1), T(0));
+        if (ck >= 0 && ccol >= 0 && (ck >> 8) == (ccol >> 8)) return cx<T>(T(0), T(0));      // inside a cluster: no first-order correction
+        return cdiv(G[(long)k * n + col], G[(long)col * n + col] - G[(long)k * n + k]);
+    };
+    cx<T> v;
+    if (cj >= 0) {
+        const RefineClusters<T>& Tb = tab[b];
+        const int c = cj >> 8, pos = cj & 255, m = Tb.size[c];
+        v = cx<T>(T(0), T(0));
+        for (int r = 0; r < m; ++r) cfma(v, entry(Tb.member[c][r], cj), Tb.X[c][r * RCM + pos]);
+    } else {
+        v = entry(j, -1);
+    }
+    Mall[((long)b * n + k) * n + j] = v;
+}
+
+template <class T>
+__global__ void refine_or_info_kernel(const int* __restrict__ flags, const int* __restrict__ linfo, int* __restrict__ any, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && (flags[b] != 0 || linfo[b] != 0)) atomicOr(any, 1);
+}
+
+}  // namespace
+
+static int g_refine_steps = 2;
+int refine_set_knob(const char* key, int value) {
+    if (std::string(key) != "eig_refine" || value < 0 || value > 4) return TRX_ERR_ARG;
+    g_refine_steps = value == 0 ? 2 : value;
+    return TRX_OK;
+}
+int refine_steps() { return g_refine_steps; }
+
+// A: balanced fp64 input (kept intact); V32 / w32: its fp32 eigendecomposition.  On return w, V hold the refined fp64 eigenpairs of A
+// (unit 2-norm is restored by the caller together with the undo of the balancing); *host_any != 0: some matrix was flagged.
+template <class T>
+int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const cx<float>* V32, const cx<float>* w32, cx<T>* w, cx<T>* V, int n, int batch, int steps,
+               int* host_any) {
+    const cx<T> one(T(1), T(0)), zero(T(0), T(0));
+    const long nn = (long)n * n;
+    cx<T>* buf[2] = {V, R.V1};
+    int cur = (steps & 1) ? 1 : 0;                 // so that the last step writes the caller's V
+    const long cntV = nn * batch, cntw = (long)n * batch;
+    TRX_LAUNCH((cvt_kernel<float, T>), dim3(cdiv_i(cntV, 256)), dim3(256), 0, s, V32, buf[cur], cntV);
+    TRX_LAUNCH((cvt_kernel<float, T>), dim3(cdiv_i(cntw, 256)), dim3(256), 0, s, w32, w, cntw);
+    if (hipMemsetAsync(R.flags, 0, sizeof(int) * (batch + 1), s) != hipSuccess) return TRX_ERR_LAUNCH;
+    for (int it = 0; it < steps; ++it) {
+        cx<T>* Vc = buf[cur];
+        cx<T>* Vn = buf[cur ^ 1];
+        // G = V^-1 (A V)
+        int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, A, n, nn, Vc, n, nn, zero, R.G, n, nn, batch); if (rc) return rc;
+        if (hipMemcpyAsync(Vn, Vc, sizeof(cx<T>) * cntV, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        rc = lu_factor<T>(s, Vn, n, nn, n, R.piv, batch, R.linfo); if (rc) return rc;
+        rc = lu_solve<T>(s, Vn, n, nn, n, R.piv, R.G, n, nn, n, batch); if (rc) return rc;
+        TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
+        TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.eoff, R.lmax);
+        TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<T>*)R.G, (const cx<T>*)w, n, (const T*)R.eoff, (const T*)R.lmax, R.partner, R.flags);
+        TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), 0, s, (const cx<T>*)R.G, n, w, (const int*)R.partner, R.clus, (RefineClusters<T>*)R.pairX, R.flags);
+        TRX_LAUNCH((refine_build_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, (const cx<T>*)R.G, n, (const int*)R.clus, (const RefineClusters<T>*)R.pairX, R.M);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Vc, n, nn, R.M, n, nn, zero, Vn, n, nn, batch); if (rc) return rc;
+        cur ^= 1;
+    }
+    TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
+    if (hipMemcpyAsync(host_any, R.flags + batch, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (getenv("TRX_EIG_DEBUG")) {
+        std::vector<int> hf(batch + 1), hl(batch);
+        std::vector<T> he(batch), hm(batch);
+        (void)hipMemcpy(hf.data(), R.flags, sizeof(int) * (batch + 1), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hl.data(), R.linfo, sizeof(int) * batch, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(he.data(), R.eoff, sizeof(T) * batch, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hm.data(), R.lmax, sizeof(T) * batch, hipMemcpyDeviceToHost);
+        std::vector<int> hp((size_t)batch * n);
+        (void)hipMemcpy(hp.data(), R.partner, sizeof(int) * (size_t)batch * n, hipMemcpyDeviceToHost);
+        for (int b = 0; b < batch; b += (batch >= 8 ? batch / 8 : 1)) {
+            int np_ = 0, nm = 0;
+            for (int i = 0; i < n; ++i) { np_ += hp[(size_t)b * n + i] >= 0; nm += hp[(size_t)b * n + i] == -2; }
+            fprintf(stderr, "libtrx eig_refine: matrix %d: %d indices in pairs, %d multi-coupled\n", b, np_, nm);
+        }
+        int f1 = 0, f2 = 0, fl = 0, f32 = 0, f64 = 0, f128 = 0, f256 = 0;
+        for (int b = 0; b < batch; ++b) { f1 += (hf[b] & 1) != 0; f2 += (hf[b] & 2) != 0; fl += hl[b] != 0; f32 += (hf[b] & 32) != 0; f64 += (hf[b] & 64) != 0; f128 += (hf[b] & 128) != 0; f256 += (hf[b] & 256) != 0; }
+        fprintf(stderr, "libtrx eig_refine: cluster failures: > %d coupled indices %d, cluster > %d: %d, cluster count / singleton %d, small solver %d\n", RCL, f32, RCM, f64, f128, f256);
+        fprintf(stderr, "libtrx eig_refine: n %d batch %d steps %d: any %d | matrices flagged: far-off %d, multi-coupled %d, LU %d | last step: max|E| %.3e max|lambda| %.3e (matrix 0), %.3e %.3e (matrix %d)\n",
+                n, batch, steps, hf[batch], f1, f2, fl, (double)he[0], (double)hm[0], (double)he[batch - 1], (double)hm[batch - 1], batch - 1);
+    }
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template int eig_refine<double>(hipStream_t, const RefineBuffers<double>&, const cx<double>*, const cx<float>*, const cx<float>*, cx<double>*, cx<double>*, int, int, int, int*);
+
+}  // namespace trx

@@ -142,9 +142,15 @@ class Engine:
         return X
 
     # -- a7 --------------------------------------------------------------------------------------------
-    def eig(self, A, destroy=False):
-        """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14)."""
+    def eig(self, A, destroy=False, refine_steps=0):
+        """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14).
+
+        refine_steps: Newton steps of libtrx's mixed-precision route (complex128 input of at least 256 rows: fp32 eigendecomposition
+        refined in fp64, include/trx.h "eig_refine"); 0 = the library default (2: the accuracy class of the all-fp64 pipeline; measured on
+        MI355X, one step is NOT enough for the 1e-5 gate of a complex64 problem at order [15,15] -- the fp32 start of this pipeline leaves
+        max |E| ~ 2e-2 ... 2e-1 there)."""
         self._check(A)
+        self.lib.check(self.lib.tuning(b"eig_refine", int(refine_steps)))
         A = self._c(A) if destroy else A.clone()
         B, n, _ = A.shape
         dt = A.dtype

@@ -34,7 +34,7 @@ class Eig(torch.autograd.Function):
         was_real = not torch.is_complex(xb)
         if was_real:
             xb = xb.to(torch.complex128 if xb.dtype == torch.float64 else torch.complex64)
-        w, V = eng.eig(xb.contiguous())
+        w, V = eng.eig(xb.contiguous(), refine_steps=3)      # differentiable path: always the three-step (all-fp64 class) refinement
         ctx.batched = x.dim() == 3
         ctx.was_real = was_real
         ctx.save_for_backward(w, V)
