@@ -256,23 +256,32 @@ def layer_solve_roof(n, precision):
 
 
 _BOUND = {"gemm_mfma_kernel<N,N>": "mfma", "gemm_mfma_kernel<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm",
-          "invit_solve_kernel": "mfma"}      # fp64 VECTOR FMAs: on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TF)
+          "invit_solve_kernel": "mfma",      # fp64 VECTOR FMAs: on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TF)
+          "gemm_mfma_kernel<N,N> fp32": "mfma", "gemm_mfma_kernel<other ops> fp32": "mfma"}
+# kernels of the eigensolver proper: with the mixed-precision route (libtrx default for complex128 input, n >= 256, batch >= 8) they run in fp32
+_EIG_STAGE = ("apply_window_kernel", "qr_prepare_kernel", "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel")
 
 
-def roofline(engine, args, elapsed, steps, n, units_per_step):
+def eig_is_mixed(args, n, chunk):
+    return args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
+
+
+def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
     """Live figures from the HIP events libtrx recorded (on the launch streams, uniformly sampled) during the timed region."""
     import ctypes
     peak_tf = PEAK_TFLOPS[args.precision]
     kernels = []
-    for tag in range(9):
+    for tag in range(11):
         buf = (ctypes.c_double * 6)()
         engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
         launches, timed, flops_t, bytes_t, ms, flops_all = list(buf)
         if timed <= 0 or ms <= 0:          # not launched, or no usable event timing (CPU emulator)
             continue
         name = engine.lib.prof_tag_name(tag).decode()
+        fp32_kernel = name.endswith("fp32") or args.precision == "native" or (name in _EIG_STAGE and eig_is_mixed(args, n, chunk))
+        peak_tf = PEAK_TFLOPS["native" if fp32_kernel else "high"]
         avg_us = 1e3 * ms / timed
-        k = {"kernel": name, "launches": int(launches), "timed_launches": int(timed), "avg_us": avg_us,
+        k = {"kernel": name, "launches": int(launches), "timed_launches": int(timed), "avg_us": avg_us, "arithmetic": "fp32" if fp32_kernel else "fp64",
              "est_total_ms_per_step": avg_us * launches / 1e3 / steps, "sum_over_wall": avg_us * launches / 1e6 / elapsed}
         bound = _BOUND.get(name)
         if name == "apply_window_kernel" and flops_all > 0:
@@ -290,7 +299,7 @@ def roofline(engine, args, elapsed, steps, n, units_per_step):
             # one wave / one workgroup per matrix, dependent chain of small steps: no meaningful flop or byte rate
             k.update(bound="hbm", achieved=0.0, peak=PEAK_HBM_GBS, unit="GB/s", note="latency-bound (one wave or workgroup per matrix)")
         k["frac"] = k["achieved"] / k["peak"]
-        if name in ("apply_window_kernel", "gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>") and args.precision == "high" and k["achieved"] > 0:
+        if name in ("apply_window_kernel", "gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>") and not fp32_kernel and k["achieved"] > 0:
             # fp64 path: 3M complex product, three real MFMAs where the 8-flops-per-complex-MAC count has four
             k["issued_mfma_tflops"] = 0.75 * k["achieved"]
             k["issued_mfma_frac"] = 0.75 * k["frac"]
@@ -328,7 +337,10 @@ def profile_fracs(k, args, peak):
     if not work or args.config != 2:
         return out
     name = k["kernel"]
-    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float")}.get(name, name.split("<")[0])
+    if "other ops" in name:          # several instantiations under one tag: no single kernel of the trace to hold it against
+        return out
+    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float"),
+           "gemm_mfma_kernel<N,N> fp32": "gemm_mfma_kernel<float, 0, 0", "apply_window_kernel": "apply_window_"}.get(name, name.split("<")[0])
     for field, fn, dur in (("frac_rocprof", "%s_kernel_profile.json" % PROFILE_TAG, lambda v: v["avg_us"]),
                            ("frac_alone", "%s_pmc_bench.json" % PROFILE_TAG, lambda v: 1e3 * v["ms_total"] / max(v["launches"], 1))):
         try:
@@ -484,7 +496,7 @@ def main():
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
-    roof = roofline(engine, args, elapsed, args.steps, n, len(idx) * layers_per_point) if rank == 0 else None
+    roof = roofline(engine, args, elapsed, args.steps, n, len(idx) * layers_per_point, chunk) if rank == 0 else None
     if args.host_profile and rank == 0:
         import cProfile
         import pstats
@@ -529,7 +541,9 @@ def main():
             "metric": "RCWA layer-solves/sec (complex64 I/O) at Fourier order [%d,%d]" % (args.order, args.order),
             "value": value, "unit": "layer-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "c128" if args.config == 5 else ("c128 arithmetic (fp64 MFMA; complex64 I/O)" if args.precision == "high" else "c64"),
+            "dtype": "c128" if args.config == 5 else (("c128 results (mixed-precision eigensolver: fp32 eigendecomposition refined to fp64 by two Newton steps of fp64 GEMMs + LU; "
+                                                        "everything else fp64 MFMA); complex64 I/O" if eig_is_mixed(args, n, chunk) else "c128 arithmetic (fp64 MFMA; complex64 I/O)")
+                                                       if args.precision == "high" else "c64"),
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
                        "chunk": int(chunk), "streams": args.streams,

@@ -19,7 +19,9 @@ static int eig_vec_env() {
 static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
 bool eig_uses_invit(int n) { return g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2; }
 // mixed-precision route (fp32 eigendecomposition + Newton refinement in fp64, eig_refine.hip): fp64 problems of at least 256 rows
-bool eig_uses_mixed(int n, size_t elem) { return elem == 8 && ((g_eig_vec == 3 && n >= 8) || (g_eig_vec == 0 && n >= 256)); }
+// Automatic: batches of at least 8 (measured, n = 1922: +6 % of the whole layer-solve step at batch 16, 64 and 128; a single n = 5202
+// matrix, whose fp64 solve is a latency chain that fp32 does not shorten, loses 60 % to the extra refinement work).
+bool eig_uses_mixed(int n, int batch, size_t elem) { return elem == 8 && ((g_eig_vec == 3 && n >= 8) || (g_eig_vec == 0 && n >= 256 && batch >= 8)); }
 int eig_set_knob(const char* key, int value) {
     if (std::string(key) != "eig_vec" || value < 0 || value > 3) return TRX_ERR_ARG;
     g_eig_vec = value;
@@ -64,7 +66,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
     tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
-    if (eig_uses_mixed(n, sizeof(T))) tot += mixed_extra_bytes(n, batch);
+    if (eig_uses_mixed(n, batch, sizeof(T))) tot += mixed_extra_bytes(n, batch);
     return tot;
 }
 
@@ -79,7 +81,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.mixedM = nullptr;
     Bf.mixed_pool = nullptr;
     Bf.mixed_pool_bytes = 0;
-    if (eig_uses_mixed(n, sizeof(T))) {
+    if (eig_uses_mixed(n, batch, sizeof(T))) {
         // X | M | spill: the fp32 pool of the mixed route overlaps X (later G) and M, which are first written after it is dead
         const size_t xm = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
         Bf.mixedM = (cx<T>*)take(e * B * N * N);
@@ -110,7 +112,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = nullptr;
     Bf.r_eoff = Bf.r_lmax = nullptr;
     Bf.r_pairX = nullptr;
-    if (eig_uses_mixed(n, sizeof(T))) {
+    if (eig_uses_mixed(n, batch, sizeof(T))) {
         Bf.r_piv = (int*)take(sizeof(int) * B * N);
         Bf.r_partner = (int*)take(sizeof(int) * B * N);
         Bf.r_linfo = (int*)take(sizeof(int) * (B + 1));
@@ -152,7 +154,7 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     int rc = balance<T>(s, B, n, batch);          // A <- D^-1 A D (zgebal 'S'); undone on the eigenvectors in schur_vectors
     if (rc) return rc;
     if constexpr (sizeof(T) == 8) {
-        if (eig_uses_mixed(n, sizeof(T))) {
+        if (eig_uses_mixed(n, batch, sizeof(T))) {
             // Mixed-precision route (eig_refine.hip): the balanced matrix stays intact in fp64; its fp32 copy goes through the fp32 pipeline
             // (which balances once more: a no-op up to rounding) and the result is refined by Newton steps made of fp64 GEMMs and one LU.
             const size_t Bn = batch, N = n;

@@ -392,7 +392,8 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
     // algorithmic work of this launch: 8 real flops per complex MAC; bytes = A + B read once, C written (+read if beta)
     const double macs = (double)m * n * k * batch * (b_upper ? 0.5 : 1.0);
     const double el = (double)sizeof(cx<T>) * batch;
-    ProfScope prof((opA == TRX_OP_N && opB == TRX_OP_N) ? PROF_GEMM_NN : PROF_GEMM_OTHER, s, desc ? 0.0 : 8.0 * macs,
+    const bool nn = opA == TRX_OP_N && opB == TRX_OP_N;
+    ProfScope prof(sizeof(T) == 8 ? (nn ? PROF_GEMM_NN : PROF_GEMM_OTHER) : (nn ? PROF_GEMM_NN_F32 : PROF_GEMM_OTHER_F32), s, desc ? 0.0 : 8.0 * macs,
                    desc ? 0.0 : el * ((double)m * k + (double)k * n + (double)m * n * ((beta.x != T(0) || beta.y != T(0)) ? 2 : 1)));
     switch (opA) {
         case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
