@@ -458,6 +458,12 @@ def main():
         # the 288 GB (3.96 vs 3.44 layer-solves/s in chunks of 32: 114 GB); a smaller device falls back to 32
         big = EMU or torch.cuda.get_device_properties(device).total_memory >= 280e9
         chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 64 if big else 32, 4: 256, 5: 1}[args.config]))
+        if args.config == 3 and chunk > 32 and not EMU and "TRX_EIG_VEC" not in os.environ:
+            # the mixed-precision eigensolver keeps one more n^2 buffer per matrix (14 GB at chunk 64): with it the 64-point chunk ran out
+            # of memory in the star product (profiles/r03_slowbox/bench_config3_chunk64_oom.err); the measured 3.96 layer-solves/s at
+            # chunk 64 is the all-fp64 route, so that is what this configuration runs (chunks <= 32 keep the library default)
+            engine.lib.check(engine.lib.tuning(b"eig_vec", 1))
+            os.environ["TRX_EIG_VEC"] = "1"          # read by eig_is_mixed() for the labels of the line
         out = None
         for w in range(warmup):
             try:
@@ -558,6 +564,8 @@ def main():
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
                        "chunk": int(chunk), "streams": args.streams,
+                       "eig_route": ("mixed: fp32 eigendecomposition + fp64 Newton refinement" if eig_is_mixed(args, n, chunk) else
+                                     "fp64 (Hessenberg, multi-shift QR, Schur vectors)") if args.precision == "high" else "fp32 (Hessenberg, multi-shift QR, Schur vectors)",
                        "precision": args.precision, "backend": ("gloo" if EMU else "nccl (RCCL)") if world > 1 else None},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "gathered_points": int(full.shape[0]),
             "numerical_failures": 0, "hbm": mem, "csrc_sha16": csrc_sha16(),

@@ -43,3 +43,32 @@ def test_gradient_matches_reference(backend, stable, bp, tag):
     assert np.abs(gr - ref).max() / np.abs(ref).max() < 1e-6
     gt_ref = float(np.asarray(g[f"{tag}_grad_thick"]).reshape(-1)[0])
     assert abs(float(thick.grad.reshape(-1)[0]) - gt_ref) / abs(gt_ref) < 1e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gradient_through_forced_q_branch(backend):
+    """avoid_Pinv_instability on the differentiable path (rcwa.py:1249-1262): with a threshold below rounding noise every layer takes
+    V = Q W Kz^-1; mathematically the same V, so FoM and gradient must agree with the P-solve branch -- and the discarded P-solve
+    (evaluated on the identity for those points) must leave no trace in the gradient."""
+    import torcwa_amd
+    eng = make_engine(backend)
+    g = np.load(os.path.join(GOLDEN, "grad_o32.npz"))
+    eps_si = complex(g["eps_si"])
+    res = []
+    for kw in ({}, {"avoid_Pinv_instability": True, "max_Pinv_instability": 1e-17}):
+        rho = torch.from_numpy(g["rho"]).to(eng.device).requires_grad_(True)
+        sim = torcwa_amd.rcwa(freq=1 / 532., order=[3, 2], L=[700., 300.], dtype=torch.complex128, engine=eng, **kw)
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        sim.add_layer(thickness=300., eps=rho * eps_si + (1. - rho))
+        sim.solve_global_smatrix()
+        t = sim.S_parameters(orders=[1, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+        fom = (torch.abs(t) ** 2).sum()
+        fom.backward()
+        res.append((float(fom.detach()), rho.grad.cpu().numpy()))
+        if kw:
+            assert len(sim.Pinv_instability) == 1 and float(sim.Pinv_instability[0]) < 1e-10
+    (f0, g0), (f1, g1) = res
+    assert np.isfinite(g1).all()
+    assert abs(f1 - f0) / abs(f0) < 1e-9
+    assert np.abs(g1 - g0).max() / np.abs(g0).max() < 1e-6

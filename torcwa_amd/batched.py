@@ -313,7 +313,8 @@ class BatchedRCWA:
         eng, N, n = self.engine, self.order_N, self.n
         P, W, kz, d = self.P[-1], self.E_eigvec[-1], self.kz_norm[-1], self.thickness[-1]
         X = torch.exp(1j * (self.omega * d)[:, None] * kz)                              # [B, n]
-        V = ag.SolveFn.apply(P, W * kz[:, None, :], eng)                                # P^-1 W Kz
+        WKz = W * kz[:, None, :]
+        bad = None
         if self.avoid_Pinv_instability:                                                 # rcwa.py:1249-1262 (metrics are detached diagnostics)
             with torch.no_grad():
                 Pd, Qd = P.detach(), self.Q[-1].detach()
@@ -325,8 +326,17 @@ class BatchedRCWA:
             self.Pinv_instability.append(ins)
             self.Qinv_instability.append(qins)
             bad = ins >= self.max_Pinv_instability
-            if bool(bad.any()):                                                         # V = Q W Kz^-1 for the ill-conditioned points
-                V = torch.where(bad[:, None, None], ag.GemmFn.apply(self.Q[-1], (W / kz[:, None, :]).contiguous(), eng), V)
+            bad = bad if bool(bad.any()) else None
+        if bad is None:
+            V = ag.SolveFn.apply(P, WKz, eng)                                           # P^-1 W Kz
+        else:
+            # V = Q W Kz^-1 for the ill-conditioned points.  The reference routes the graph of such a point through that branch only;
+            # in a batch both branches are evaluated, so the discarded P-solve of a bad point must not be able to produce Inf / NaN
+            # (0 * NaN in SolveFn.backward would poison the gradient of every point): those points solve with the identity instead
+            sel = bad[:, None, None]
+            I = torch.eye(n, dtype=self._cdtype, device=self._device)
+            V = torch.where(sel, ag.GemmFn.apply(self.Q[-1], (W / kz[:, None, :]).contiguous(), eng),
+                            ag.SolveFn.apply(torch.where(sel, I, P), WKz, eng))
         p11, p12, p21, p22 = [t.to(self._cdtype)[:, :, None] for t in self._Vfinv.d]
         F = torch.cat((p11 * V[:, :N] + p12 * V[:, N:], p21 * V[:, :N] + p22 * V[:, N:]), dim=1)    # Vf^-1 V
         A_, B_ = W + F, (W - F) * X[:, None, :]
