@@ -313,3 +313,40 @@ def test_eig_mixed_precision_fallback(backend):
             assert info[b] == 0
             assert np.abs(A[sl][b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A[sl][b]).max() < 1e-12
         assert np.linalg.cond(V[0]) < 1e6
+
+
+@pytest.mark.gpu
+def test_eig_two_host_threads_small_batches():
+    """Two host threads, each on its own HIP stream, call trx_eig with batches below 8 (one iteration group, run on the CALLER's stream):
+    every call borrows a lane (pinned progress summary + events) from the process-wide pool and must hand it back only after the
+    look-ahead iteration it queued has drained -- otherwise the other thread's call can pick the lane up and read a stale 'no active
+    matrix left' summary, ending its QR phase early with info == 0.  Results are checked on every call."""
+    import threading
+    import torch
+    from torcwa_amd.engine import Engine
+    eng = Engine()
+    dev = eng.device
+    rng = np.random.default_rng(4711)
+    mats = [torch.from_numpy((rng.standard_normal((3, n, n)) + 1j * rng.standard_normal((3, n, n))).astype(np.complex128)).to(dev) for n in (70, 101, 88, 120)]
+    errors, worst = [], [0.0, 0.0]
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                for it in range(10):
+                    A = mats[(2 * it + t) % len(mats)]
+                    w, V = eng.eig(A)
+                    res = (torch.linalg.norm(A @ V - V * w[:, None, :], dim=(1, 2)) / torch.linalg.norm(A, dim=(1, 2))).max()
+                    worst[t] = max(worst[t], float(res))
+                st.synchronize()
+        except BaseException as e:      # noqa: BLE001 - reported on the test's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert max(worst) < 1e-12, worst
