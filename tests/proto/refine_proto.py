@@ -3,7 +3,7 @@ each step has to run.  TEST INFRASTRUCTURE (prototype); never imported by the pr
 
     python tests/proto/refine_proto.py [order] [lambda_nm]
 
-Start: LAPACK cgeev (fp32) eigenpairs of A = P Q of the bench layer (a-Si:H rectangle 180 x 100 nm, 300 nm cell, glass input).
+Start: LAPACK cgeev (true single precision, through scipy) eigenpairs of A = P Q of the bench layer (a-Si:H rectangle 180 x 100 nm, 300 nm cell, glass input).
 Step in precision p: G = V^-1 (A V), lambda = diag G, pairs with |G_ij| + |G_ji| > 0.1 |lambda_j - lambda_i| are coupled (their connected
 components are diagonalised exactly from their block of G), F_ij = G_ij / (lambda_j - lambda_i) elsewhere, V <- V (I + F) R.
 Schedules compared: 64,64 (the library default), 32,64 (first step in fp32), 32,64,64, 64 alone, 32 alone.
@@ -14,6 +14,7 @@ import sys
 import os
 
 import numpy as np
+import scipy.linalg as sl          # numpy.linalg computes complex64 problems in DOUBLE and rounds the result; scipy calls cgeev / cgesv
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -50,7 +51,8 @@ def components(n, pairs):
 def newton_step(A, V, prec):
     ct = np.complex64 if prec == 32 else np.complex128
     A_, V_ = A.astype(ct), V.astype(ct)
-    G = np.linalg.solve(V_, A_ @ V_)
+    G = sl.solve(V_, A_ @ V_)
+    assert G.dtype == ct
     lam = np.diag(G).copy()
     n = G.shape[0]
     a1 = np.abs(G.real) + np.abs(G.imag)
@@ -105,7 +107,8 @@ def main():
     A = bench_operator(order, lam_nm)
     n = A.shape[0]
     ref = np.linalg.eigvals(A)
-    w32, V32 = np.linalg.eig(A.astype(np.complex64))
+    w32, V32 = sl.eig(A.astype(np.complex64))
+    assert V32.dtype == np.complex64
     print("order [%d,%d], n = %d, lambda = %.0f nm; |eig| up to %.3g; fp32 start: residual %.2e, eigenvalue error %.2e"
           % (order, order, n, lam_nm, np.abs(ref).max(), residual(A, w32.astype(np.complex128), V32.astype(np.complex128)), eigenvalue_error(w32, ref)))
     for sched in ((64, 64), (32, 64), (32, 64, 64), (64,), (32,), (32, 32, 64)):
