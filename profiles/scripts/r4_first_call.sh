@@ -1,0 +1,37 @@
+#!/bin/bash
+# First GPU call of round 4 (≈8 min): what round 3 could not take at its final sources, then the knob sweep of the QR phase in the regime
+# the mixed-precision route created (fp32 first stage: the QR phase is latency-bound, its four iteration groups overlap only 1.6-fold).
+#   usage: bash profiles/scripts/r4_first_call.sh > gpurun_out/r4_first_call.txt 2>&1
+R=$GRAFT_REPO_ROOT
+cd $R
+# 1. HBM counters of the default bench command (two passes, one counter each; never combined with other trace domains)
+timeout 600 bash profiles/scripts/pmc_bench.sh 128 $R/gpurun_out/r04_pmc_bench.json > gpurun_out/r04_pmc_bench.txt 2>&1
+tail -20 gpurun_out/r04_pmc_bench.txt
+cd $R
+export TRX_BENCH_NOPROF=1
+run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(round(d['value'],3), round(d['ms_per_step'],1), d.get('numerical_failures'))"; }
+echo "== batch 128, mixed route: slab launch width (co-residency of the chase / AED workgroups of the other groups), groups, AED window"
+EXTRA=""
+run X=0
+run TRX_SLAB_WGS=384
+run TRX_SLAB_WGS=256
+run TRX_SLAB_WGS=192
+run TRX_SLAB_WGS=128
+run TRX_QR_GROUPS=8
+run TRX_QR_GROUPS=8 TRX_SLAB_WGS=128
+run TRX_QR_GROUPS=2
+run TRX_QR_AED=48
+run TRX_SLAB_DYN=1
+echo "== two half-batches on two streams (host threads): the latency-bound QR phase of one under the GEMM phases of the other"
+EXTRA="--streams 2"
+run X=0
+run TRX_QR_GROUPS=2
+echo "== batch 16"
+EXTRA="--batch 16"
+run X=0
+run TRX_QR_GROUPS=1
+run TRX_QR_GROUPS=4
+run TRX_QR_AED=64
