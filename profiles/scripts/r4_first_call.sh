@@ -25,6 +25,10 @@ run TRX_QR_GROUPS=8 TRX_SLAB_WGS=128
 run TRX_QR_GROUPS=2
 run TRX_QR_AED=48
 run TRX_SLAB_DYN=1
+# two / three bulge chains per sweep: a third fewer outer iterations (= AEDs) for a third more slab work, which is cheap in fp32
+run TRX_QR_CHAINS=2
+run TRX_QR_CHAINS=3
+run TRX_QR_CHAINS=2 TRX_SLAB_WGS=256
 echo "== two half-batches on two streams (host threads): the latency-bound QR phase of one under the GEMM phases of the other"
 EXTRA="--streams 2"
 run X=0
@@ -35,3 +39,4 @@ run X=0
 run TRX_QR_GROUPS=1
 run TRX_QR_GROUPS=4
 run TRX_QR_AED=64
+run TRX_QR_CHAINS=2
