@@ -200,6 +200,38 @@ def excerpt(path, at_frac=0.55, span_us=1500.0):
             print(f"  s{sid}  {(a - lo) / 1e3:9.1f}  {(b - a) / 1e3:8.1f}  {nm.split('<')[0]:24s} ({gx},{gy})")
 
 
+def lanes(path, at_frac=0.55, span_ms=30.0, bucket_us=100.0):
+    """One text row per stream over span_ms from the point at_frac of the trace, one character per bucket of bucket_us: the kernel
+    kind that was busy longest in the bucket (P qr_prepare, W qr_window, A apply_window, G gemm, H hess_*, L lu_* / trsm, o other,
+    '.' idle).  Shows at a glance which iteration groups of the QR phase run and which wait."""
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.cursor().execute("pragma table_info(kernels)")]
+    qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
+    rows = sorted((a, b, short(nm), sid) for nm, a, b, sid in con.cursor().execute(f"select name, start, end, {qcol} from kernels"))
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    lo = t0 + at_frac * (t1 - t0)
+    hi = lo + span_ms * 1e6
+    nb = int(span_ms * 1e3 / bucket_us)
+    kinds = (("qr_prepare", "P"), ("qr_window", "W"), ("apply_window", "A"), ("gemm", "G"), ("hess_", "H"), ("lu_", "L"), ("trsm", "L"))
+    per = {}
+    for a, b, nm, sid in rows:
+        if b < lo or a > hi:
+            continue
+        ch = next((c for key, c in kinds if key in nm), "o")
+        acc = per.setdefault(sid, [dict() for _ in range(nb)])
+        i0, i1 = max(0, int((a - lo) / (bucket_us * 1e3))), min(nb - 1, int((b - lo) / (bucket_us * 1e3)))
+        for i in range(i0, i1 + 1):
+            b_lo, b_hi = lo + i * bucket_us * 1e3, lo + (i + 1) * bucket_us * 1e3
+            ov = min(b, b_hi) - max(a, b_lo)
+            if ov > 0:
+                acc[i][ch] = acc[i].get(ch, 0) + ov
+    print(f"# stream lanes, {span_ms:.0f} ms from t = {(lo - t0) / 1e6:.1f} ms, one character per {bucket_us:.0f} us (stream column: {qcol})")
+    for sid in sorted(per):
+        row = "".join((max(d.items(), key=lambda kv: kv[1])[0] if d else ".") for d in per[sid])
+        busy = sum(sum(d.values()) for d in per[sid]) / (span_ms * 1e6)
+        print(f"  s{sid} {100 * busy:5.1f}% |{row}|")
+
+
 def to_json(path, out, batch, command):
     """Per-kernel averages of the trace as JSON, stamped with the hash of the kernel sources (bench.py reads it back for the
     `frac_rocprof` figure of its roofline block and refuses it on other sources)."""
@@ -222,6 +254,8 @@ if __name__ == "__main__":
         to_json(sys.argv[1], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
     elif len(sys.argv) > 2 and sys.argv[2] == "--excerpt":
         excerpt(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else 0.55)
+    elif len(sys.argv) > 2 and sys.argv[2] == "--lanes":
+        lanes(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else 0.55, float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
     elif len(sys.argv) > 2 and sys.argv[2] == "--concurrency":
         concurrency(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "--gaps-frac":
