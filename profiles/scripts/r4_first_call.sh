@@ -8,6 +8,12 @@ cd $R
 timeout 600 bash profiles/scripts/pmc_bench.sh 128 $R/gpurun_out/r04_pmc_bench.json > gpurun_out/r04_pmc_bench.txt 2>&1
 tail -20 gpurun_out/r04_pmc_bench.txt
 cd $R
+# 2. kernel trace with the per-stream lane view: in round 3 every iteration group was busy only 40 % of the QR phase, in idle periods of
+#    more than 5 ms, and no two sweeps and no two AEDs of different groups ever ran together (profiles/r03_bench_final_concurrency.txt) --
+#    the lanes show whether the groups pair up on shared hardware queues (s0/s2, s1/s3) or starve on the host
+timeout 300 bash profiles/scripts/trace_bench.sh r04_first
+head -12 gpurun_out/r04_first_lanes.txt | cut -c1-260
+cd $R
 export TRX_BENCH_NOPROF=1
 run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
 import sys,json
@@ -25,6 +31,10 @@ run TRX_QR_GROUPS=8 TRX_SLAB_WGS=128
 run TRX_QR_GROUPS=2
 run TRX_QR_AED=48
 run TRX_SLAB_DYN=1
+# hardware queues of the process (read by the HIP runtime at start-up): 4 by default, streams beyond that share a queue and serialise
+run GPU_MAX_HW_QUEUES=8
+run GPU_MAX_HW_QUEUES=8 TRX_QR_GROUPS=8
+run GPU_MAX_HW_QUEUES=2
 # two / three bulge chains per sweep: a third fewer outer iterations (= AEDs) for a third more slab work, which is cheap in fp32
 run TRX_QR_CHAINS=2
 run TRX_QR_CHAINS=3
