@@ -172,8 +172,21 @@ def run_step_topopt(rho0, order, engine):
     return fom.detach().to(torch.complex128).reshape(1, 1)
 
 
+_side_stream = [None]
+
+
 def run_step(freq, grids, order, engine, args, chunk):
     from torcwa_amd.sweep import solve_single_layer_sweep, solve_stack_sweep
+    if os.environ.get("TRX_BENCH_SIDE_STREAM") and freq is not None and freq.device.type == "cuda" and torch.cuda.current_stream(freq.device) == torch.cuda.default_stream(freq.device):
+        # experiment (profiles/scripts/r4_first_call.sh): run the step on a created stream instead of the legacy null stream, i.e. put
+        # iteration group 0 of trx_eig's QR phase on another hardware queue than the one the null stream owns
+        if _side_stream[0] is None:
+            _side_stream[0] = torch.cuda.Stream(device=freq.device)
+        _side_stream[0].wait_stream(torch.cuda.current_stream(freq.device))
+        with torch.cuda.stream(_side_stream[0]):
+            out = run_step(freq, grids, order, engine, args, chunk)
+        torch.cuda.current_stream(freq.device).wait_stream(_side_stream[0])
+        return out
     if args.config == 5:
         return run_step_topopt(grids, order, engine)
     if args.config == 3:

@@ -35,6 +35,9 @@ run TRX_SLAB_DYN=1
 run GPU_MAX_HW_QUEUES=8
 run GPU_MAX_HW_QUEUES=8 TRX_QR_GROUPS=8
 run GPU_MAX_HW_QUEUES=2
+# the step on a created stream instead of the null stream (shifts which hardware queue group 0 shares)
+run TRX_BENCH_SIDE_STREAM=1
+run TRX_BENCH_SIDE_STREAM=1 GPU_MAX_HW_QUEUES=8
 # two / three bulge chains per sweep: a third fewer outer iterations (= AEDs) for a third more slab work, which is cheap in fp32
 run TRX_QR_CHAINS=2
 run TRX_QR_CHAINS=3
