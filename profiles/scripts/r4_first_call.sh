@@ -13,6 +13,8 @@ cd $R
 #    the lanes show whether the groups pair up on shared hardware queues (s0/s2, s1/s3) or starve on the host
 timeout 300 bash profiles/scripts/trace_bench.sh r04_first
 head -12 gpurun_out/r04_first_lanes.txt | cut -c1-260
+# 2b. the host side of the same question: HIP runtime API trace of one step (no counters)
+timeout 300 bash profiles/scripts/api_trace.sh r04_first
 cd $R
 export TRX_BENCH_NOPROF=1
 run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
