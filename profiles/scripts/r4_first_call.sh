@@ -16,6 +16,12 @@ head -12 gpurun_out/r04_first_lanes.txt | cut -c1-260
 # 2b. the host side of the same question: HIP runtime API trace of one step (no counters)
 timeout 300 bash profiles/scripts/api_trace.sh r04_first
 cd $R
+# 2c. the host loop of the QR phase with spin kernels instead of the real ones (tests/micro/group_loop.hip, built in-tree before the call:
+#     hipcc --offload-arch=gfx950 -O2 -o tests/micro/_build/group_loop tests/micro/group_loop.hip): 1 / 2 / 4 groups, slab width, null
+#     stream or not, with and without the memset + memcpy of the summary
+for cfg in "1 512 1 0" "2 512 1 0" "4 512 1 0" "4 512 0 0" "4 512 1 1" "4 128 1 0" "4 128 0 1" "8 512 0 0"; do tests/micro/_build/group_loop $cfg; done
+GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 4 512 1 0
+GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 8 512 0 0
 export TRX_BENCH_NOPROF=1
 run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
 import sys,json
