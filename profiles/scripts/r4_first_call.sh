@@ -8,7 +8,7 @@ cd $R
 timeout 600 bash profiles/scripts/pmc_bench.sh 128 $R/gpurun_out/r04_pmc_bench.json > gpurun_out/r04_pmc_bench.txt 2>&1
 tail -20 gpurun_out/r04_pmc_bench.txt
 cd $R
-# 2. kernel trace with the per-stream lane view: in round 3 every iteration group was busy only 40 % of the QR phase, in idle periods of
+# 2. kernel trace with the per-stream lane view: UNDER THE TRACER every iteration group of round 3 was busy only 40 % of the QR phase, in idle periods of
 #    more than 5 ms, and no two sweeps and no two AEDs of different groups ever ran together (profiles/r03_bench_final_concurrency.txt) --
 #    the lanes show whether the groups pair up on shared hardware queues (s0/s2, s1/s3) or starve on the host
 timeout 300 bash profiles/scripts/trace_bench.sh r04_first
