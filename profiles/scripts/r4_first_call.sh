@@ -22,6 +22,9 @@ cd $R
 for cfg in "1 512 1 0" "2 512 1 0" "4 512 1 0" "4 512 0 0" "4 512 1 1" "4 128 1 0" "4 128 0 1" "8 512 0 0"; do tests/micro/_build/group_loop $cfg; done
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 4 512 1 0
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 8 512 0 0
+# 2d. where the fp64 GEMM loses the matrix pipe (0.59 issued): the ladder from a register-only MFMA loop to the full slab staging
+#     (hipcc --offload-arch=gfx950 -O3 -o tests/micro/_build/mfma_ladder tests/micro/mfma_ladder.hip before the call)
+timeout 120 tests/micro/_build/mfma_ladder
 export TRX_BENCH_NOPROF=1
 run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
 import sys,json
