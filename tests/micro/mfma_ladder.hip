@@ -7,7 +7,10 @@
 //   level 1  + operands read from LDS every k-step (8 ds_read_b64 per wave: 2 A fragments + 2 B fragments, real and imaginary planes)
 //   level 2  + the 3M operand sums (Ar + Ai, Br + Bi: 4 v_add_f64)
 //   level 3  + two workgroup barriers per K slab of 4 k-steps
-//   level 4  + the slab's global loads (64 x 16 + 16 x 64 complex128 per workgroup = 32 KB) and LDS stores, register-staged
+//   level 4  + the slab's global loads (64 x 16 + 16 x 64 complex128 per workgroup = 32 KB) and LDS stores, register-staged: loads issued
+//            before the MFMAs, first used after them (a true prefetch)
+//   level 5  = level 4 with the loaded registers touched right behind the loads, as the round-3 GEMM kernel does (its zeroing select of
+//            out-of-range elements sits there: hipcc waits for the whole slab before the MFMAs)
 //   hipcc --offload-arch=gfx950 -O3 -o tests/micro/_build/mfma_ladder tests/micro/mfma_ladder.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +38,11 @@ __global__ __launch_bounds__(256, 2) void ladder_kernel(const double2* __restric
 #pragma unroll
             for (int q = 0; q < 8; ++q) stage[q] = src[g + q * 256];                   // 8 x 16 B per thread = the slab's 32 KB per workgroup
             g += 2048; if (g >= src_elems - 8 * 256) g -= (src_elems - 8 * 256);
+            if (LEVEL >= 5) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(stage[q].x), "+v"(stage[q].y));       // first use right here
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMAs (hipcc otherwise sinks them to their first use)
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void ladder_kernel(const double2* __restric
                     acc[3 * (2 * i + j) + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc[3 * (2 * i + j) + 2], 0, 0, 0);
                 }
         }
+        if (LEVEL >= 4) __builtin_amdgcn_sched_barrier(0);
         if (LEVEL >= 3) __syncthreads();
         if (LEVEL >= 4) {
 #pragma unroll
@@ -110,5 +119,6 @@ int main() {
     if (run<2>(cus, src, src_elems, out, "+ 3M operand sums")) return 1;
     if (run<3>(cus, src, src_elems, out, "+ 2 barriers per K slab")) return 1;
     if (run<4>(cus, src, src_elems, out, "+ global loads and LDS stores of the slab")) return 1;
+    if (run<5>(cus, src, src_elems, out, "same, loads consumed before the MFMAs")) return 1;
     return 0;
 }
