@@ -33,6 +33,11 @@ print(round(d['value'],3), round(d['ms_per_step'],1), d.get('numerical_failures'
 echo "== batch 128, mixed route: slab launch width (co-residency of the chase / AED workgroups of the other groups), groups, AED window"
 EXTRA=""
 run X=0
+# MORE slab workgroups: the fp32 slab kernel needs 108 VGPRs and 35 KB of LDS, so four workgroups fit on a CU where the default grid
+# (512) places two; per wave a strip is claim (atomic with return, ~1.5 us exposed) + 16 loads (~2 us exposed) + MFMAs + stores
+run TRX_SLAB_WGS=1024
+run TRX_SLAB_WGS=768
+run TRX_SLAB_WGS=1024 TRX_SLAB_SPW=2
 run TRX_SLAB_WGS=384
 run TRX_SLAB_WGS=256
 run TRX_SLAB_WGS=192
