@@ -11,6 +11,8 @@
 //            before the MFMAs, first used after them (a true prefetch)
 //   level 5  = level 4 with the loaded registers touched right behind the loads, as the round-3 GEMM kernel does (its zeroing select of
 //            out-of-range elements sits there: hipcc waits for the whole slab before the MFMAs)
+//   level 6  = level 4 with every k-step's MFMAs issued twice: the arithmetic intensity of a tile twice as large (half the bytes per flop) --
+//            if the utilisation jumps, the 64 x 64 tile is bound by the operand traffic (385 GB per 1922^3 x 128 GEMM at 3.9 TB/s), not by latency
 //   hipcc --offload-arch=gfx950 -O3 -o tests/micro/_build/mfma_ladder tests/micro/mfma_ladder.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void ladder_kernel(const double2* __restric
 #pragma unroll
             for (int q = 0; q < 8; ++q) stage[q] = src[g + q * 256];                   // 8 x 16 B per thread = the slab's 32 KB per workgroup
             g += 2048; if (g >= src_elems - 8 * 256) g -= (src_elems - 8 * 256);
-            if (LEVEL >= 5) {
+            if (LEVEL == 5) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(stage[q].x), "+v"(stage[q].y));       // first use right here
             }
@@ -57,6 +59,8 @@ __global__ __launch_bounds__(256, 2) void ladder_kernel(const double2* __restric
             double as[2], bs[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) { as[i] = LEVEL >= 2 ? ar[i] + ai[i] : ar[i]; bs[i] = LEVEL >= 2 ? br[i] + bi[i] : br[i]; }
+#pragma unroll
+            for (int rep = 0; rep < (LEVEL == 6 ? 2 : 1); ++rep)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -100,7 +104,7 @@ static int run(int cus, const double2* src, long src_elems, double* out, const c
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             best = ms < best ? ms : best;
         }
-        const double flops = 2.0 * 16 * 16 * 4 * 12 * 4.0 * slabs * 4 * grid;      // real MFMA flops
+        const double flops = 2.0 * 16 * 16 * 4 * 12 * 4.0 * slabs * 4 * grid * (LEVEL == 6 ? 2 : 1);      // real MFMA flops
         printf("level %d (%s), %d workgroup(s) per CU: %8.2f ms, %6.1f TFLOP/s issued = %.3f of 78.6\n", LEVEL, what, per_cu, best, flops / best * 1e-9, flops / best * 1e-9 / 78.6);
     }
     return 0;
@@ -120,5 +124,6 @@ int main() {
     if (run<3>(cus, src, src_elems, out, "+ 2 barriers per K slab")) return 1;
     if (run<4>(cus, src, src_elems, out, "+ global loads and LDS stores of the slab")) return 1;
     if (run<5>(cus, src, src_elems, out, "same, loads consumed before the MFMAs")) return 1;
+    if (run<6>(cus, src, src_elems, out, "level 4 at twice the flops per byte")) return 1;
     return 0;
 }
