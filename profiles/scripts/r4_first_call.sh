@@ -4,6 +4,9 @@
 #   usage: bash profiles/scripts/r4_first_call.sh > gpurun_out/r4_first_call.txt 2>&1
 R=$GRAFT_REPO_ROOT
 cd $R
+# the micro-benchmarks (built here if the in-tree binaries did not travel; same image, hipcc present)
+mkdir -p tests/micro/_build
+for m in group_loop mfma_ladder; do [ -x tests/micro/_build/$m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tests/micro/_build/$m tests/micro/$m.hip 2>/dev/null; done
 # 1. HBM counters of the default bench command (two passes, one counter each; never combined with other trace domains)
 timeout 600 bash profiles/scripts/pmc_bench.sh 128 $R/gpurun_out/r04_pmc_bench.json > gpurun_out/r04_pmc_bench.txt 2>&1
 tail -20 gpurun_out/r04_pmc_bench.txt
