@@ -30,6 +30,10 @@ print(round(d['value'],3), round(d['ms_per_step'],1), d.get('numerical_failures'
 echo "== batch 128, mixed route: slab launch width (co-residency of the chase / AED workgroups of the other groups), groups, AED window"
 EXTRA=""
 run X=0
+# wave priority of the chase / AED kernels (branch r4-prep)
+run TRX_QR_PRIO=3
+run TRX_QR_PRIO=1
+run TRX_QR_PRIO=3 TRX_SLAB_WGS=256
 run TRX_SLAB_WGS=384
 run TRX_SLAB_WGS=256
 run TRX_SLAB_WGS=192
