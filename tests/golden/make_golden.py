@@ -216,7 +216,7 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--grad", "--fullsize", "--geometry", "--rayleigh")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--fields-larger", "--grad", "--fullsize", "--geometry", "--rayleigh")):
     main()
 
 
@@ -287,8 +287,34 @@ def main_fields():
                inc=20 * np.pi / 180, azi=35 * np.pi / 180, angle_layer="output")
 
 
+def _layers_of(z):
+    lays = []
+    for li in range(int(z["n_layers"])):
+        vals = []
+        for nm in ("eps", "mu"):
+            if f"L{li}_{nm}_grid" in z.files:
+                vals.append(torch.from_numpy(z[f"L{li}_{nm}_grid"]))
+            else:
+                v = complex(z[f"L{li}_{nm}_scalar"])
+                vals.append(v.real if v.imag == 0 else v)
+        lays.append((float(z[f"L{li}_thickness"]), vals[0], vals[1]))
+    return lays
+
+
+def main_fields_larger():
+    """Field maps at larger orders, on the inputs of existing S-matrix fixtures: the single layer at [5,5] (n = 242) and the 6-layer
+    stack of config 3 at [8,8] (n = 578; fields inside every one of its patterned and homogeneous layers)."""
+    for name, src in (("example1_o5", "example1_o5_c128"), ("config3_o8_l500", "config3_o8_l500_c128f32")):
+        z = np.load(os.path.join(HERE, src + ".npz"))
+        field_case(name, freq=float(z["freq"]), order=[int(v) for v in z["order"]], L=[float(v) for v in z["L"]], layers=_layers_of(z),
+                   eps_in=float(np.real(z["eps_in"])) if bool(z["has_in"]) else None, eps_out=float(np.real(z["eps_out"])) if bool(z["has_out"]) else None,
+                   inc=float(z["inc"]), azi=float(z["azi"]), angle_layer=str(z["angle_layer"]))
+
+
 if __name__ == "__main__" and "--fields" in sys.argv:
     main_fields()
+if __name__ == "__main__" and "--fields-larger" in sys.argv:
+    main_fields_larger()
 
 
 # ---------------------------------------------------------------------------------------------------------

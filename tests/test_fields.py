@@ -1,6 +1,7 @@
 """Sources and field maps (torcwa/rcwa.py:526-1112) of the drop-in class against golden vectors from the reference.
 
-Fixtures: tests/golden/fields_*.npz (make_golden.py --fields): E_i of three sources (plane wave xy/forward, plane wave
+Fixtures: tests/golden/fields_*.npz (make_golden.py --fields, --fields-larger: orders [3,3], [3,2], [5,5] and the 6-layer stack of
+config 3 at [8,8]): E_i of three sources (plane wave xy/forward, plane wave
 ps/backward, Fourier source), field_xz / field_yz on z samples in every region incl. layer boundaries, field_xy in the
 input half-space, first/last layer and output half-space.  Tolerance 1e-8 relative to the largest field value
 (c128 run vs c128 golden; eigen-decomposition conditioning limits it).
@@ -18,12 +19,20 @@ SRCS = {"planewave_xy_f": ("pw", dict(amplitude=[1.0, 0.5j], direction="forward"
         "fourier_xy_f": ("fo", dict(amplitude=[[1.0, 0.2], [0.1j, 0.4]], orders=[[0, 0], [1, -1]], direction="f", notation="xy"))}
 
 
+# (fixture, dtype tag of the S-matrix fixture holding its inputs, runs on the CPU emulator): the 6-layer stack at [8,8] (three patterned
+# layers of n = 578) takes ten minutes on the emulator -- validated there once (TRX_TEST_SLOW_EMU=1), run on the GPU only
+FIELD_CASES = [("example1_o3", "c128", True), ("asym_o32", "c128", True), ("example1_o5", "c128", True), ("config3_o8_l500", "c128f32", False)]
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", ["example1_o3", "asym_o32"])
-def test_fields_against_reference(backend, name):
+@pytest.mark.parametrize("name,tag,emu_ok", FIELD_CASES, ids=[c[0] for c in FIELD_CASES])
+def test_fields_against_reference(backend, name, tag, emu_ok):
     import os
+    if backend == "emu" and not emu_ok and not os.environ.get("TRX_TEST_SLOW_EMU"):
+        pytest.skip("too slow for the CPU suite (validated on the emulator once, runs on the GPU)")
     eng = make_engine(backend)
-    g = load_case(name, "c128")
+    g = load_case(name, tag)
+    tol = 1e-8 if emu_ok else 1e-7          # the 6-layer stack passes 1e-8 on the emulator; a decade of slack for another summation order
     f = np.load(os.path.join(GOLDEN, f"fields_{name}.npz"))
     sim = run_case(eng, g, "c128")
     x, y, z = (torch.from_numpy(f[k]) for k in ("x", "y", "z"))
@@ -39,14 +48,14 @@ def test_fields_against_reference(backend, name):
             got = np.stack([t.cpu().numpy() for t in E + H])
             ref = f[f"{sname}_{plane}"]
             assert got.shape == ref.shape
-            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-8, (sname, plane)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < tol, (sname, plane)
         for ln in (-1, 0, nl - 1, nl):
             key = f"{sname}_xy_L{ln}"
             if key not in f:
                 continue
             E, H = sim.field_xy(int(ln), x, y, float(f[key + "_zprop"]))
             got = np.stack([t.cpu().numpy() for t in E + H])
-            assert np.abs(got - f[key]).max() / np.abs(f[key]).max() < 1e-8, (sname, ln)
+            assert np.abs(got - f[key]).max() / np.abs(f[key]).max() < tol, (sname, ln)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
