@@ -58,44 +58,47 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDMB;
 
     cx<T> ra[RA], rb[RB];
-    // Branch-free tile loads: out-of-range coordinates are clamped to a valid address and the value is zeroed by a
-    // select, so the global_load_dwordx4 of a slab issue back-to-back instead of each sitting in its own exec branch.
+    // Branch-free tile loads: out-of-range coordinates are clamped to a valid address, so the global_load_dwordx4 of a slab issue
+    // back-to-back instead of each sitting in its own exec branch.  The loaded registers are NOT touched here: the zeroing of the
+    // out-of-range elements (and the conjugation) happens in store_tiles(), one K slab of MFMAs later -- a select right behind the load
+    // made hipcc wait for the whole slab (s_waitcnt vmcnt(7..0)) BEFORE the MFMAs it was meant to run under, i.e. the "prefetch" exposed
+    // the full load latency once per slab and wave (ISA of round 3).
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
             const int row = A_KC ? (e / BK) : (e % BM), kk = A_KC ? (e % BK) : (e / BM);
-            const bool ok = (m0 + row < m) && (k0 + kk < k);
             const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
             // 32-bit element offsets from the block-uniform base (scalar base + vector offset addressing: one register per load
             // instead of two); the host checks that a matrix spans less than 2^31 elements
-            cx<T> v = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
-            if (OPA == TRX_OP_C) v.y = -v.y;
-            ra[r] = ok ? v : cx<T>(T(0), T(0));
+            ra[r] = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
             const int col = B_KC ? (e / BK) : (e % BN), kk = B_KC ? (e % BK) : (e / BN);
-            const bool ok = (n0 + col < n) && (k0 + kk < k);
             const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            cx<T> v = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
-            if (OPB == TRX_OP_C) v.y = -v.y;
-            rb[r] = ok ? v : cx<T>(T(0), T(0));
+            rb[r] = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int k0) {             // k0: the slab the registers were loaded for
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
             const int row = A_KC ? (e / BK) : (e % BM), ka = A_KC ? (e % BK) : (e / BM);
-            Ar[row * sAr + ka * sAk] = ra[r].x; Ai[row * sAr + ka * sAk] = ra[r].y;
+            const bool ok = (m0 + row < m) && (k0 + ka < k);
+            cx<T> v = ra[r];
+            if (OPA == TRX_OP_C) v.y = -v.y;
+            Ar[row * sAr + ka * sAk] = ok ? v.x : T(0); Ai[row * sAr + ka * sAk] = ok ? v.y : T(0);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
             const int col = B_KC ? (e / BK) : (e % BN), kb = B_KC ? (e % BK) : (e / BN);
-            Br[col * sBc + kb * sBk] = rb[r].x; Bi[col * sBc + kb * sBk] = rb[r].y;
+            const bool ok = (n0 + col < n) && (k0 + kb < k);
+            cx<T> v = rb[r];
+            if (OPB == TRX_OP_C) v.y = -v.y;
+            Br[col * sBc + kb * sBk] = ok ? v.x : T(0); Bi[col * sBc + kb * sBk] = ok ? v.y : T(0);
         }
     };
 
@@ -113,15 +116,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     const int col_l = lane & 15;
     load_tiles(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
-        store_tiles();
+        store_tiles(k0);
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);          // the next slab's loads are issued here, ahead of this slab's MFMAs, and first used after them
         // 16 k-values at a time: bounds the unrolled fragment prefetch (a 32-deep unroll spills)
 #pragma unroll 1
         for (int kh = 0; kh < BK; kh += 16) {
             if constexpr (M3) cmma3_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI, accX);
             else cmma_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
     if constexpr (M3) {
