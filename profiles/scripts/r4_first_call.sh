@@ -22,6 +22,9 @@ cd $R
 for cfg in "1 512 1 0" "2 512 1 0" "4 512 1 0" "4 512 0 0" "4 512 1 1" "4 128 1 0" "4 128 0 1" "8 512 0 0"; do tests/micro/_build/group_loop $cfg; done
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 4 512 1 0
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 8 512 0 0
+# 2e. GEMM shapes of the hot path (branch r4-prep: prefetch fix in the kernel; knob gemm_xcd = XCD-aware tile order)
+python tests/gpu_gemm_bench.py 2>&1 | grep -v amdgpu
+TRX_GEMM_XCD=1 python tests/gpu_gemm_bench.py 2>&1 | grep -v amdgpu
 export TRX_BENCH_NOPROF=1
 run() { echo -n "$* : "; env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg $EXTRA 2>/dev/null | python -c "
 import sys,json
