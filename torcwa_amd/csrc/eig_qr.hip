@@ -73,6 +73,15 @@ __device__ __forceinline__ void rot_cols(const Rot<T>& R, cx<T>& x, cx<T>& y) {
     x = nx; y = ny;
 }
 
+// 1 / sqrt(x) for the rotation generator.  rsqrt(float) resolves to the DOUBLE overload in HIP: the fp32 kernels of round 3 carried, per
+// call, v_cvt_f64_f32 + v_rsq_f64 + a five-instruction fp64 refinement + v_cvt_f32_f64 -- twice per rotation, on the critical path of every
+// chain step.  A plain v_rsq_f32 (1 ulp, or refined in fp32) is cheaper but leaves the rotations unitary to only ~5 ulp, and the
+// eigen-refinement behind the fp32 solver feels that (exactly degenerate spectra: 1e-8 instead of 1e-14 after two Newton steps, emulator).
+// So fp32 takes ONE unrefined v_rsq_f64 of the fp64 argument: good to ~2^-26, i.e. correctly rounded for a float, no under / overflow of
+// the product |f|^2 d^2, five dependent instructions.
+__device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ float fast_rsqrt_f64arg(double x) { return (float)__builtin_amdgcn_rsq(x); }
+
 // Fast rotation generator for the chase (no hypot/divide chain: two rsqrt).  |f|^2+|g|^2 cannot overflow here: the
 // entries of a balanced RCWA operator are O(1e3) and negligible subdiagonals were flushed to zero by the deflation scan.
 template <class T>
@@ -80,13 +89,13 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     Rot<T> R;
     const T ag2 = norm2(g), af2 = norm2(f);
     if (ag2 == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
-    if (af2 == T(0)) { const T ig = rsqrt(ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
+    if (af2 == T(0)) { const T ig = (sizeof(T) == 8) ? (T)fast_rsqrt((double)ag2) : (T)fast_rsqrt_f64arg((double)ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
     const T n2 = af2 + ag2;
     T tu;                                          // 1 / (|f| d)
     if (sizeof(T) == 8) {
-        tu = rsqrt(af2 * n2);                      // one rsqrt on the critical path (fp64 range: |f|^2 d^2 cannot under/overflow here)
+        tu = (T)fast_rsqrt((double)(af2 * n2));    // one rsqrt on the critical path (fp64 range: |f|^2 d^2 cannot under/overflow here)
     } else {
-        tu = rsqrt(n2) * rsqrt(af2);               // fp32: keep the factors apart (their product could underflow)
+        tu = (T)fast_rsqrt_f64arg((double)af2 * (double)n2);      // fp32: the product is formed in fp64 (it could underflow in fp32)
     }
     R.c = af2 * tu;                                // |f| / d
     R.s = tu * (f * conj(g));                      // (f/|f|) conj(g) / d
