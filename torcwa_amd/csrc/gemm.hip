@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         // 16 k-values at a time: bounds the unrolled fragment prefetch (a 32-deep unroll spills)
 #pragma unroll 1
         for (int kh = 0; kh < BK; kh += 16) {
+            // a wave whose 16-row band lies entirely below the matrix (the last tile row of m = 1922 = 30 x 64 + 2 has two valid rows, of
+            // m = 961 one) issues no MFMAs: wave-uniform, so no per-MFMA predicate; it still loads, stores and meets the barriers
+            if (m0 + arow0 >= m) continue;
             if constexpr (M3) cmma3_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI, accX);
             else cmma_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI);
         }
