@@ -471,12 +471,8 @@ def main():
         # the 288 GB (3.96 vs 3.44 layer-solves/s in chunks of 32: 114 GB); a smaller device falls back to 32
         big = EMU or torch.cuda.get_device_properties(device).total_memory >= 280e9
         chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 64 if big else 32, 4: 256, 5: 1}[args.config]))
-        if args.config == 3 and chunk > 32 and not EMU and "TRX_EIG_VEC" not in os.environ:
-            # the mixed-precision eigensolver keeps one more n^2 buffer per matrix (14 GB at chunk 64): with it the 64-point chunk ran out
-            # of memory in the star product (profiles/r03_slowbox/bench_config3_chunk64_oom.err); the measured 3.96 layer-solves/s at
-            # chunk 64 is the all-fp64 route, so that is what this configuration runs (chunks <= 32 keep the library default)
-            engine.lib.check(engine.lib.tuning(b"eig_vec", 1))
-            os.environ["TRX_EIG_VEC"] = "1"          # read by eig_is_mixed() for the labels of the line
+        # (round 3 forced the all-fp64 route here: the mixed route's extra n^2 buffer did not fit at chunk 64; the refinement now builds its
+        # update matrix in place, so the library default applies -- to be confirmed by the config-3 run)
         out = None
         for w in range(warmup):
             try:

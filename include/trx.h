@@ -86,6 +86,7 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   "slab_dyn"    1 static / 2 dynamically claimed strips (TRX_SLAB_DYN)              auto: dynamic for groups of >= 16 matrices
  *   "slab_wgs"    32-4096 workgroups per dynamic off-window launch (TRX_SLAB_WGS)     auto: 512
  *   "slab_pipe"   2 = software-pipelined off-window kernel (TRX_SLAB_PIPE)            auto: off (measured slower)
+ *   "qr_prio"     wave priority 1-3 (s_setprio) of the window-chase and AED kernels (TRX_QR_PRIO)   auto: 0 = default priority
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chain unitary
  *   Eigenvector route of trx_eig
  *   "eig_vec"     1 = all-fp64 pipeline with Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR
@@ -100,6 +101,10 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
+ *   GEMM (trx_gemm and every product inside the library)
+ *   "gemm_dma"    1 = fp64 general tile fed by a direct-to-LDS ring (TRX_GEMM_DMA)   auto: off (measured equal)
+ *   "gemm_xcd"    1 = general tile launched in XCD-aware order: the workgroups one XCD runs together take 8 x 8 neighbouring tiles of one
+ *                       matrix (TRX_GEMM_XCD)                                            auto: off (not yet measured)
  *   Hessenberg reduction: TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
 int trx_tuning(const char* key, int value);
 

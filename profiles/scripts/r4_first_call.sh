@@ -22,9 +22,12 @@ cd $R
 # 2c. the host loop of the QR phase with spin kernels instead of the real ones (tests/micro/group_loop.hip, built in-tree before the call:
 #     hipcc --offload-arch=gfx950 -O2 -o tests/micro/_build/group_loop tests/micro/group_loop.hip): 1 / 2 / 4 groups, slab width, null
 #     stream or not, with and without the memset + memcpy of the summary
-for cfg in "1 512 1 0" "2 512 1 0" "4 512 1 0" "4 512 0 0" "4 512 1 1" "4 128 1 0" "4 128 0 1" "8 512 0 0"; do tests/micro/_build/group_loop $cfg; done
+for cfg in "4 512 1 0" "8 512 0 0"; do tests/micro/_build/group_loop $cfg; done
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 4 512 1 0
 GPU_MAX_HW_QUEUES=8 tests/micro/_build/group_loop 8 512 0 0
+# 2e. GEMM shapes of the hot path (branch r4-prep: prefetch fix in the kernel; knob gemm_xcd = XCD-aware tile order)
+python tests/gpu_gemm_bench.py 2>&1 | grep -v amdgpu
+TRX_GEMM_XCD=1 python tests/gpu_gemm_bench.py 2>&1 | grep -v amdgpu
 # 2d. where the fp64 GEMM loses the matrix pipe (0.59 issued): the ladder from a register-only MFMA loop to the full slab staging
 #     (hipcc --offload-arch=gfx950 -O3 -o tests/micro/_build/mfma_ladder tests/micro/mfma_ladder.hip before the call)
 timeout 120 tests/micro/_build/mfma_ladder
@@ -36,6 +39,11 @@ print(round(d['value'],3), round(d['ms_per_step'],1), d.get('numerical_failures'
 echo "== batch 128, mixed route: slab launch width (co-residency of the chase / AED workgroups of the other groups), groups, AED window"
 EXTRA=""
 run X=0
+run TRX_GEMM_XCD=1
+# wave priority of the chase / AED kernels (branch r4-prep)
+run TRX_QR_PRIO=3
+run TRX_QR_PRIO=1
+run TRX_QR_PRIO=3 TRX_SLAB_WGS=256
 # MORE slab workgroups: the fp32 slab kernel needs 108 VGPRs and 35 KB of LDS, so four workgroups fit on a CU where the default grid
 # (512) places two; per wave a strip is claim (atomic with return, ~1.5 us exposed) + 16 loads (~2 us exposed) + MFMAs + stores
 run TRX_SLAB_WGS=1024

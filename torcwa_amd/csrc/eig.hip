@@ -32,19 +32,20 @@ int eig_set_knob(const char* key, int value) {
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 static size_t eig_ws_bytes_f32(int n, int batch) { return eig_ws_bytes_t<float>(n, batch); }
 
-// Mixed route, on top of the all-fp64 layout: Z doubles as the second eigenvector buffer and X as G; extra: M [B,n,n] + pivots / flags /
-// pairs + the fp32 pool (A32, V32, w32, the fp32 eigensolver's own workspace), which is dead before G and M are first written and
-// therefore overlaps them where it can (X and M are carved adjacent: pool = X | M | spill).
+// Mixed route, on top of the all-fp64 layout: Z doubles as the second eigenvector buffer and X as G, which the update matrix (I + F) R then
+// overwrites in place; extra: pivots / flags / cluster tables / the saved diagonal + whatever the fp32 pool (A32, the fp32 eigensolver's own
+// workspace, V32, w32) needs beyond Z | X, which it overlaps: the pool is dead before the refinement first writes them, except V32 / w32,
+// which sit at its END (behind Z in any case: the first conversion may write Z while it reads them).
 static size_t mixed_pool_bytes(int n, int batch) {
     const size_t B = batch, N = n;
-    return eig_ws_bytes_f32(n, batch) + 2 * al256(8 * B * N * N) + al256(8 * B * N);
+    return al256(8 * B * N * N) + al256(eig_ws_bytes_f32(n, batch)) + al256(8 * B * N * N) + al256(8 * B * N);
 }
 static size_t mixed_extra_bytes(int n, int batch) {
     const size_t B = batch, N = n, e = 16;
-    const size_t xm = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
-    size_t tot = al256(e * B * N * N);                                        // M
-    if (pool > xm) tot += al256(pool - xm);                                    // spill of the fp32 pool beyond X | M
-    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(REFINE_CLUSTER_BYTES * B);
+    const size_t zx = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
+    size_t tot = 0;
+    if (pool > zx) tot += al256(pool - zx);                                    // spill of the fp32 pool beyond Z | X
+    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(REFINE_CLUSTER_BYTES * B) + al256(e * B * N);
     return tot;
 }
 
@@ -78,16 +79,14 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.A = (cx<T>*)A;
     Bf.Z = (cx<T>*)take(e * B * N * N);
     Bf.X = (cx<T>*)take(e * B * N * N);
-    Bf.mixedM = nullptr;
     Bf.mixed_pool = nullptr;
     Bf.mixed_pool_bytes = 0;
     if (eig_uses_mixed(n, batch, sizeof(T))) {
-        // X | M | spill: the fp32 pool of the mixed route overlaps X (later G) and M, which are first written after it is dead
-        const size_t xm = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
-        Bf.mixedM = (cx<T>*)take(e * B * N * N);
-        if (pool > xm) (void)take(pool - xm);
-        Bf.mixed_pool = (char*)Bf.X;
-        Bf.mixed_pool_bytes = pool > xm ? pool : xm;
+        // Z | X | spill: the fp32 pool of the mixed route overlaps Z (later the second eigenvector buffer) and X (later G)
+        const size_t zx = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
+        if (pool > zx) (void)take(pool - zx);
+        Bf.mixed_pool = (char*)Bf.Z;
+        Bf.mixed_pool_bytes = pool > zx ? pool : zx;
     }
     Bf.Ht = nullptr; Bf.SW = nullptr;
     if (eig_uses_invit(n)) { Bf.Ht = (cx<T>*)take(e * B * N * N); Bf.SW = (unsigned char*)take(B * N * N); }
@@ -112,6 +111,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = nullptr;
     Bf.r_eoff = Bf.r_lmax = nullptr;
     Bf.r_pairX = nullptr;
+    Bf.r_d0 = nullptr;
     if (eig_uses_mixed(n, batch, sizeof(T))) {
         Bf.r_piv = (int*)take(sizeof(int) * B * N);
         Bf.r_partner = (int*)take(sizeof(int) * B * N);
@@ -120,6 +120,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
         Bf.r_eoff = (T*)take(8 * B);
         Bf.r_lmax = (T*)take(8 * B);
         Bf.r_pairX = (cx<T>*)take(REFINE_CLUSTER_BYTES * B);
+        Bf.r_d0 = (cx<T>*)take(e * B * N);
     }
 }
 
@@ -160,15 +161,15 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             const size_t Bn = batch, N = n;
             char* p = B.mixed_pool;
             cx<float>* A32 = (cx<float>*)p; p += al256(8 * Bn * N * N);
-            cx<float>* V32 = (cx<float>*)p; p += al256(8 * Bn * N * N);
-            cx<float>* w32 = (cx<float>*)p; p += al256(8 * Bn * N);
-            void* ws32 = p;
+            void* ws32 = p; p += al256(eig_ws_bytes_f32(n, batch));
+            cx<float>* V32 = (cx<float>*)p; p += al256(8 * Bn * N * N);           // behind Z: A32 and the fp32 solver's Z32 alone fill it
+            cx<float>* w32 = (cx<float>*)p;
             rc = eig_mixed_convert(s, (const cx<double>*)A, A32, (long)Bn * N * N);
             if (rc) return rc;
             rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32);      // (its info is folded into the flags below)
             if (rc) return rc;
             RefineBuffers<T> R;
-            R.G = B.X; R.M = B.mixedM; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;
+            R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;
             R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
             int any = 0;
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)

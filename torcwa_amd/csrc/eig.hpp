@@ -56,19 +56,19 @@ struct EigBuffers {
     QrState* st;   // [B]
     int* summary;  // [64]: 8 ints per iteration group of the QR phase (up to 8 groups)
     // mixed-precision route (fp64 only; null otherwise)
-    cx<T>* mixedM;             // [B,n,n] directly behind X
-    char* mixed_pool;          // fp32 pool = X | M | spill
+    char* mixed_pool;          // fp32 pool = Z | X | spill
     size_t mixed_pool_bytes;
     int *r_piv, *r_linfo, *r_flags, *r_partner;
     T *r_eoff, *r_lmax;
     cx<T>* r_pairX;
+    cx<T>* r_d0;               // [B,n] diagonal of G
 };
 
 // buffers of the mixed-precision route (eig_refine.hip): fp32 eigendecomposition + Newton refinement in fp64
 template <class T>
 struct RefineBuffers {
-    cx<T>* G;        // [B,n,n]  A V, then V^-1 A V
-    cx<T>* M;        // [B,n,n]  (I + F) R
+    cx<T>* G;        // [B,n,n]  A V, then V^-1 A V, then (in place) the update matrix (I + F) R
+    cx<T>* d0;       // [B,n]    diagonal of V^-1 A V (the in-place build overwrites it in G)
     cx<T>* V1;       // [B,n,n]  second eigenvector buffer (LU copy, then the next iterate)
     int* piv;        // [B,n]
     int* linfo;      // [B]

@@ -44,6 +44,13 @@ constexpr int SM = 64;             // largest matrix the in-LDS single-wave rout
 constexpr int QAED = EigPlan::QAED;   // aggressive-early-deflation window
 constexpr int QAED_MOVES = 12;        // undeflatable eigenvalues moved out of the way per AED
 
+// s_setprio takes an immediate: 0 = leave the wave at the default priority
+__device__ __forceinline__ void wave_priority(int p) {
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+
 template <class T>
 struct Rot {
     T c;
@@ -66,6 +73,15 @@ __device__ __forceinline__ void rot_cols(const Rot<T>& R, cx<T>& x, cx<T>& y) {
     x = nx; y = ny;
 }
 
+// 1 / sqrt(x) for the rotation generator.  rsqrt(float) resolves to the DOUBLE overload in HIP: the fp32 kernels of round 3 carried, per
+// call, v_cvt_f64_f32 + v_rsq_f64 + a five-instruction fp64 refinement + v_cvt_f32_f64 -- twice per rotation, on the critical path of every
+// chain step.  A plain v_rsq_f32 (1 ulp, or refined in fp32) is cheaper but leaves the rotations unitary to only ~5 ulp, and the
+// eigen-refinement behind the fp32 solver feels that (exactly degenerate spectra: 1e-8 instead of 1e-14 after two Newton steps, emulator).
+// So fp32 takes ONE unrefined v_rsq_f64 of the fp64 argument: good to ~2^-26, i.e. correctly rounded for a float, no under / overflow of
+// the product |f|^2 d^2, five dependent instructions.
+__device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ float fast_rsqrt_f64arg(double x) { return (float)__builtin_amdgcn_rsq(x); }
+
 // Fast rotation generator for the chase (no hypot/divide chain: two rsqrt).  |f|^2+|g|^2 cannot overflow here: the
 // entries of a balanced RCWA operator are O(1e3) and negligible subdiagonals were flushed to zero by the deflation scan.
 template <class T>
@@ -73,13 +89,13 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     Rot<T> R;
     const T ag2 = norm2(g), af2 = norm2(f);
     if (ag2 == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
-    if (af2 == T(0)) { const T ig = rsqrt(ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
+    if (af2 == T(0)) { const T ig = (sizeof(T) == 8) ? (T)fast_rsqrt((double)ag2) : (T)fast_rsqrt_f64arg((double)ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
     const T n2 = af2 + ag2;
     T tu;                                          // 1 / (|f| d)
     if (sizeof(T) == 8) {
-        tu = rsqrt(af2 * n2);                      // one rsqrt on the critical path (fp64 range: |f|^2 d^2 cannot under/overflow here)
+        tu = (T)fast_rsqrt((double)(af2 * n2));    // one rsqrt on the critical path (fp64 range: |f|^2 d^2 cannot under/overflow here)
     } else {
-        tu = rsqrt(n2) * rsqrt(af2);               // fp32: keep the factors apart (their product could underflow)
+        tu = (T)fast_rsqrt_f64arg((double)af2 * (double)n2);      // fp32: the product is formed in fp64 (it could underflow in fp32)
     }
     R.c = af2 * tu;                                // |f| / d
     R.s = tu * (f * conj(g));                      // (f/|f|) conj(g) / d
@@ -317,8 +333,9 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        int sm, int wantz, long long* dbg_all = nullptr) {
+                                                        int sm, int wantz, int prio, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
+    wave_priority(prio);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
     const int SLD = sm + 1;                                      // sm: largest small matrix of this launch (AED window = small-block threshold)
@@ -580,8 +597,9 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, int prio, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
+    wave_priority(prio);            // knob qr_prio: the 16 barrier-coupled waves of a chase against the slab-update waves sharing their CU
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
@@ -1130,13 +1148,16 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     if (PART == 2 && dynamic) {
         // dynamic claiming; the next claim is issued before the current strip is processed, so that the round trip of the atomic
         // (1-2 us) hides behind a strip's worth of loads and MFMAs (a wave over-claims once at the end: harmless)
-        auto claim = [&]() {
+        // The claim's return value stays in lane 0's VGPR until the strip is done: a readfirstlane right behind the atomic (round 3) put an
+        // s_waitcnt vmcnt(0) in front of the strip's 16 loads, i.e. every strip paid the atomic's round trip AND the loads' latency one
+        // after the other; now the two are outstanding together and the scalar copy is taken behind a scheduling barrier.
+        auto claim_issue = [&]() {
             int g = 0;
             if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
-            return __builtin_amdgcn_readfirstlane(g);
+            return g;
         };
-        for (int g = claim(); g < S;) {
-            const int gn = claim();
+        for (int g = __builtin_amdgcn_readfirstlane(claim_issue()); g < S;) {
+            const int gn_v = claim_issue();
             const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
             if (band) {
                 if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
@@ -1145,7 +1166,9 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
                 if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
                 else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
             }
-            g = gn;
+            int gn_late = gn_v;
+            asm volatile("" : "+v"(gn_late) : : "memory");      // pins the first use of the claim behind the strip's stores (hipcc hoists a bare readfirstlane back to the atomic)
+            g = __builtin_amdgcn_readfirstlane(gn_late);
         }
         return;
     }
@@ -1315,7 +1338,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, prio = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1338,6 +1361,7 @@ static QrKnobs& qr_knobs() {
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
+        q.prio = geti("TRX_QR_PRIO", 0, 3, 0);                // wave priority (s_setprio) of the window-chase and AED kernels; 0 = leave the default
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1392,6 +1416,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
+    else if (s == "qr_prio") { slot = &k.prio; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1516,7 +1541,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
           TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
+                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz, K.prio,
                      (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
@@ -1534,8 +1559,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, K.prio, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, K.prio, (long long*)nullptr); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip

@@ -34,9 +34,9 @@ __global__ __launch_bounds__(256) void cvt_kernel(const cx<TI>* __restrict__ in,
     if (i < count) { const cx<TI> v = in[i]; out[i] = cx<TO>((TO)v.x, (TO)v.y); }
 }
 
-// eoff[b] = max off-diagonal |G_ij| (abs1), lmax[b] = max |G_ii|;  lam[b, i] = G_ii
+// eoff[b] = max off-diagonal |G_ij| (abs1), lmax[b] = max |G_ii|;  lam[b, i] = d0[b, i] = G_ii
 template <class T>
-__global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, T* __restrict__ eoff, T* __restrict__ lmax) {
+__global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, cx<T>* __restrict__ d0, T* __restrict__ eoff, T* __restrict__ lmax) {
     __shared__ T red[2][4];
     const int b = blockIdx.x;
     const cx<T>* G = Gall + (long)b * n * n;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restric
     for (long e = threadIdx.x; e < (long)n * n; e += blockDim.x) {
         const int i = (int)(e / n), j = (int)(e - (long)i * n);
         const T a = abs1(G[e]);
-        if (i == j) { lam[(long)b * n + i] = G[e]; lm = a > lm ? a : lm; }
+        if (i == j) { lam[(long)b * n + i] = G[e]; d0[(long)b * n + i] = G[e]; lm = a > lm ? a : lm; }
         else eo = (a > eo || !(a == a)) ? a : eo;                      // a NaN sticks
     }
     eo = wave_max(eo); lm = wave_max(lm);
@@ -315,31 +315,48 @@ __global__ __launch_bounds__(64) void refine_solve_clusters_kernel(const cx<T>* 
     }
 }
 
-// M = (I + F) R:  F_kj = G_kj / (lamd_j - lamd_k) outside the clusters (lamd = diag G), R = the eigenvector matrices of the clusters applied to their columns
+// G <- M = (I + F) R IN PLACE:  F_kj = G_kj / (d_j - d_k) outside the clusters (d = diag G, saved in d0 by the scan), R = the eigenvector
+// matrices of the clusters applied to their columns.  Two passes over disjoint entries, neither reading an entry another thread writes:
+// (1) the cluster columns, one thread per ROW: the row's entries in a cluster's columns are combined among themselves (read into
+//     registers, then overwritten);  (2) every other entry on its own.
 template <class T>
-__global__ __launch_bounds__(256) void refine_build_kernel(const cx<T>* __restrict__ Gall, int n, const int* __restrict__ clus, const RefineClusters<T>* __restrict__ tab,
-                                                           cx<T>* __restrict__ Mall) {
+__global__ __launch_bounds__(256) void refine_build_clusters_kernel(cx<T>* __restrict__ Gall, int n, const cx<T>* __restrict__ d0all, const int* __restrict__ clus,
+                                                                    const RefineClusters<T>* __restrict__ tab) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RefineClusters<T>& Tb = tab[b];
+    const int ncl = Tb.ncl;
+    if (ncl == 0) return;
+    cx<T>* Grow = Gall + ((long)b * n + k) * n;
+    const cx<T>* d0 = d0all + (long)b * n;
+    const int ck = clus[(long)b * n + k];
+    const cx<T> dk = d0[k];
+    for (int c = 0; c < ncl; ++c) {
+        const int m = Tb.size[c];
+        if (clus[(long)b * n + Tb.member[c][0]] < 0) continue;          // the small solver gave up on this cluster (matrix flagged): its columns stay ordinary ones
+        cx<T> in[RCM];
+        for (int r = 0; r < m; ++r) {
+            const int col = Tb.member[c][r];
+            if (k == col) in[r] = cx<T>(T(1), T(0));
+            else if (ck >= 0 && (ck >> 8) == c) in[r] = cx<T>(T(0), T(0));          // inside a cluster: no first-order correction
+            else in[r] = cdiv(Grow[col], d0[col] - dk);
+        }
+        for (int pos = 0; pos < m; ++pos) {
+            cx<T> v(T(0), T(0));
+            for (int r = 0; r < m; ++r) cfma(v, in[r], Tb.X[c][r * RCM + pos]);
+            Grow[Tb.member[c][pos]] = v;
+        }
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void refine_build_inplace_kernel(cx<T>* __restrict__ Gall, int n, const cx<T>* __restrict__ d0all, const int* __restrict__ clus) {
     const int b = blockIdx.z, k = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const cx<T>* G = Gall + (long)b * n * n;
-    const int* cl = clus + (long)b * n;
-    const int ck = cl[k], cj = cl[j];
-    auto entry = [&](int col, int ccol) {                               // (I + F)[k, col]
-        if (k == col) return cx<T>(T(1), T(0));
-        if (ck >= 0 && ccol >= 0 && (ck >> 8) == (ccol >> 8)) return cx<T>(T(0), T(0));      // inside a cluster: no first-order correction
-        return cdiv(G[(long)k * n + col], G[(long)col * n + col] - G[(long)k * n + k]);
-    };
-    cx<T> v;
-    if (cj >= 0) {
-        const RefineClusters<T>& Tb = tab[b];
-        const int c = cj >> 8, pos = cj & 255, m = Tb.size[c];
-        v = cx<T>(T(0), T(0));
-        for (int r = 0; r < m; ++r) cfma(v, entry(Tb.member[c][r], cj), Tb.X[c][r * RCM + pos]);
-    } else {
-        v = entry(j, -1);
-    }
-    Mall[((long)b * n + k) * n + j] = v;
+    if (clus[(long)b * n + j] >= 0) return;                 // a cluster column: written by the pass above
+    cx<T>* g = Gall + ((long)b * n + k) * n + j;
+    const cx<T>* d0 = d0all + (long)b * n;
+    *g = (k == j) ? cx<T>(T(1), T(0)) : cdiv(*g, d0[j] - d0[k]);
 }
 
 template <class T>
@@ -380,11 +397,12 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         rc = lu_factor<T>(s, Vn, n, nn, n, R.piv, batch, R.linfo); if (rc) return rc;
         rc = lu_solve<T>(s, Vn, n, nn, n, R.piv, R.G, n, nn, n, batch); if (rc) return rc;
         TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
-        TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.eoff, R.lmax);
+        TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.d0, R.eoff, R.lmax);
         TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<T>*)R.G, (const cx<T>*)w, n, (const T*)R.eoff, (const T*)R.lmax, R.partner, R.flags);
         TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), 0, s, (const cx<T>*)R.G, n, w, (const int*)R.partner, R.clus, (RefineClusters<T>*)R.pairX, R.flags);
-        TRX_LAUNCH((refine_build_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, (const cx<T>*)R.G, n, (const int*)R.clus, (const RefineClusters<T>*)R.pairX, R.M);
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Vc, n, nn, R.M, n, nn, zero, Vn, n, nn, batch); if (rc) return rc;
+        TRX_LAUNCH((refine_build_clusters_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus, (const RefineClusters<T>*)R.pairX);
+        TRX_LAUNCH((refine_build_inplace_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus);
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Vc, n, nn, R.G, n, nn, zero, Vn, n, nn, batch); if (rc) return rc;
         cur ^= 1;
     }
     TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);

@@ -29,7 +29,7 @@ constexpr int plane_of(int extent, bool k_contig, int bk) { return k_contig ? ex
 template <class T, int OPA, int OPB, int WR, int NT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
-                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
+                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper, int xs, int ys, int nb) {
     constexpr int LDK = BK + 2;
     constexpr int WC = 4 / WR;                   // waves along N
     constexpr int BM = 16 * WR, BN = 16 * NT * WC;
@@ -39,7 +39,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     __shared__ T Ai[plane_of(BM, OPA == TRX_OP_N, BK)];
     __shared__ T Br[plane_of(BN, OPB != TRX_OP_N, BK)];
     __shared__ T Bi[plane_of(BN, OPB != TRX_OP_N, BK)];
-    const int b = blockIdx.z;
+    // Tile of this workgroup.  Plain mapping: (blockIdx.x, blockIdx.y) = tile, blockIdx.z = matrix -- consecutive tiles go to different
+    // XCDs (workgroup L of a launch runs on XCD L % 8), so the 64 workgroups resident on one XCD hold 64 unrelated tiles and every operand
+    // panel is fetched from memory once per tile.  XCD-aware mapping (xs > 0, knob gemm_xcd, 1-D grid): the workgroups 8 q + c, q = 64 s ..
+    // 64 s + 63, which XCD c runs together, take the 8 x 8 tiles of ONE supertile (number 8 s + c, counted over the whole batch), so that
+    // a K slab of an A row panel or B column panel is fetched once per 8 tiles.
+    int b = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x;
+    if (xs > 0) {
+        const unsigned L = blockIdx.x, q = L >> 3;
+        const unsigned S = (q >> 6) * 8 + (L & 7), per = (unsigned)xs * ys;
+        b = (int)(S / per);
+        if (b >= nb) return;
+        const unsigned r = S - (unsigned)b * per, tt = q & 63;
+        ty = (int)(r / xs) * 8 + (int)(tt >> 3);
+        tx = (int)(r % xs) * 8 + (int)(tt & 7);
+    }
     A += (long)b * sA;
     B += (long)b * sB;
     C += (long)b * sC;
@@ -48,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         m = d.m; n = d.n; k = d.k;
         A += d.offA; B += d.offB; C += d.offC;
     }
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = ty * BM, n0 = tx * BN;
     if (m0 >= m || n0 >= n) return;
     if (b_upper && n0 + BN < k) k = n0 + BN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
     const int t = threadIdx.x;
@@ -58,44 +72,47 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDMB;
 
     cx<T> ra[RA], rb[RB];
-    // Branch-free tile loads: out-of-range coordinates are clamped to a valid address and the value is zeroed by a
-    // select, so the global_load_dwordx4 of a slab issue back-to-back instead of each sitting in its own exec branch.
+    // Branch-free tile loads: out-of-range coordinates are clamped to a valid address, so the global_load_dwordx4 of a slab issue
+    // back-to-back instead of each sitting in its own exec branch.  The loaded registers are NOT touched here: the zeroing of the
+    // out-of-range elements (and the conjugation) happens in store_tiles(), one K slab of MFMAs later -- a select right behind the load
+    // made hipcc wait for the whole slab (s_waitcnt vmcnt(7..0)) BEFORE the MFMAs it was meant to run under, i.e. the "prefetch" exposed
+    // the full load latency once per slab and wave (ISA of round 3).
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
             const int row = A_KC ? (e / BK) : (e % BM), kk = A_KC ? (e % BK) : (e / BM);
-            const bool ok = (m0 + row < m) && (k0 + kk < k);
             const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
             // 32-bit element offsets from the block-uniform base (scalar base + vector offset addressing: one register per load
             // instead of two); the host checks that a matrix spans less than 2^31 elements
-            cx<T> v = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
-            if (OPA == TRX_OP_C) v.y = -v.y;
-            ra[r] = ok ? v : cx<T>(T(0), T(0));
+            ra[r] = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
             const int col = B_KC ? (e / BK) : (e % BN), kk = B_KC ? (e % BK) : (e / BN);
-            const bool ok = (n0 + col < n) && (k0 + kk < k);
             const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            cx<T> v = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
-            if (OPB == TRX_OP_C) v.y = -v.y;
-            rb[r] = ok ? v : cx<T>(T(0), T(0));
+            rb[r] = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int k0) {             // k0: the slab the registers were loaded for
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = t + 256 * r;
             const int row = A_KC ? (e / BK) : (e % BM), ka = A_KC ? (e % BK) : (e / BM);
-            Ar[row * sAr + ka * sAk] = ra[r].x; Ai[row * sAr + ka * sAk] = ra[r].y;
+            const bool ok = (m0 + row < m) && (k0 + ka < k);
+            cx<T> v = ra[r];
+            if (OPA == TRX_OP_C) v.y = -v.y;
+            Ar[row * sAr + ka * sAk] = ok ? v.x : T(0); Ai[row * sAr + ka * sAk] = ok ? v.y : T(0);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int e = t + 256 * r;
             const int col = B_KC ? (e / BK) : (e % BN), kb = B_KC ? (e % BK) : (e / BN);
-            Br[col * sBc + kb * sBk] = rb[r].x; Bi[col * sBc + kb * sBk] = rb[r].y;
+            const bool ok = (n0 + col < n) && (k0 + kb < k);
+            cx<T> v = rb[r];
+            if (OPB == TRX_OP_C) v.y = -v.y;
+            Br[col * sBc + kb * sBk] = ok ? v.x : T(0); Bi[col * sBc + kb * sBk] = ok ? v.y : T(0);
         }
     };
 
@@ -113,15 +130,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     const int col_l = lane & 15;
     load_tiles(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
-        store_tiles();
+        store_tiles(k0);
         __syncthreads();
         if (k0 + BK < k) load_tiles(k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);          // the next slab's loads are issued here, ahead of this slab's MFMAs, and first used after them
         // 16 k-values at a time: bounds the unrolled fragment prefetch (a 32-deep unroll spills)
 #pragma unroll 1
         for (int kh = 0; kh < BK; kh += 16) {
+            // a wave whose 16-row band lies entirely below the matrix (the last tile row of m = 1922 = 30 x 64 + 2 has two valid rows, of
+            // m = 961 one) issues no MFMAs: wave-uniform, so no per-MFMA predicate; it still loads, stores and meets the barriers
+            if (m0 + arow0 >= m) continue;
             if constexpr (M3) cmma3_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI, accX);
             else cmma_tile_strided<T, NT>(Ar + kh * sAk, Ai + kh * sAk, sAr, sAk, arow0, Br + kh * sBk, Bi + kh * sBk, sBk, sBc, bcol0, 16, accR, accI);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
     if constexpr (M3) {
@@ -329,6 +351,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(int m, int n, int k, c
 // 73.3 TF-equivalent at 1922^3 x 128, 79.5 vs 80.1 at 4096^3, 29.7 vs 29.9 layer-solves/s in the bench) -- neither the load latency nor the
 // LDS stores nor the second barrier is what holds the 3M product at ~76 % of the matrix-core peak in issued MFMAs.  Default: off.
 static int gemm_dma_env() { const char* e = getenv("TRX_GEMM_DMA"); return (e && atoi(e) == 1) ? 1 : 0; }
+static int gemm_xcd_env() { const char* e = getenv("TRX_GEMM_XCD"); return e ? atoi(e) : 0; }
+static int g_gemm_xcd = gemm_xcd_env();       // trx_tuning("gemm_xcd", 0 / 1): XCD-aware tile order of the general tile (TRX_GEMM_XCD)
 static int g_gemm_dma = gemm_dma_env();       // trx_tuning("gemm_dma", 0 / 1): fp64 general tile through the direct-to-LDS ring (TRX_GEMM_DMA)
 
 template <class T, int OPA, int OPB>
@@ -337,9 +361,9 @@ void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T
     // K-slab depth 16 everywhere.  A 32-deep slab for the general tile (half the barriers per flop, twice the prefetch distance) was
     // measured SLOWER on MI355X with the 3M product (70.9 vs 72.6 TF at 1922^3 x 128: 256 VGPRs, one spill); the template keeps it.
     if (shape == 1)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
     else if (shape == 2)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
     else {
         if constexpr (sizeof(T) == 8) {
             if (g_gemm_dma) {
@@ -353,7 +377,14 @@ void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T
                 return;
             }
         }
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+        const int xs = cdiv_i(cdiv_i(n, 64), 8), ys = cdiv_i(cdiv_i(m, 64), 8);
+        const long nsuper = (long)batch * xs * ys;
+        if (g_gemm_xcd && !desc && nsuper >= 16 && nsuper < (1L << 21)) {
+            // 8 supertiles (one per XCD) x 64 tiles per group of 512 workgroups
+            TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3((unsigned)(cdiv_i(nsuper, 8) * 512)), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, xs, ys, batch);
+            return;
+        }
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
     }
 }
 
@@ -372,8 +403,10 @@ int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, 
 }  // namespace
 
 int gemm_set_knob(const char* key, int value) {
-    if (std::string(key) != "gemm_dma" || value < 0 || value > 1) return TRX_ERR_ARG;
-    g_gemm_dma = value;
+    if (value < 0 || value > 1) return TRX_ERR_ARG;
+    if (std::string(key) == "gemm_dma") g_gemm_dma = value;
+    else if (std::string(key) == "gemm_xcd") g_gemm_xcd = value;
+    else return TRX_ERR_ARG;
     return TRX_OK;
 }
 
