@@ -46,25 +46,19 @@ def build_gpu(verbose=False, force=False):
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
-    # eig_qr.hip: the strip claim of the off-window update is an atomic with return whose value is wanted one strip LATER.  hipcc's atomic
-    # optimizer rewrites every wave-uniform atomic add into "first lane adds the lane count, v_readfirstlane, per-lane offset", which puts an
-    # s_waitcnt vmcnt(0) right behind the atomic (ISA of round 3: each strip paid the atomic's round trip before it could issue its loads).
-    # All atomics of that file are issued by one lane, so nothing is lost by switching the rewrite off there.
-    per_file = {"eig_qr.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
     deps = _deps()
     objs, jobs = [], []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        fl = flags + per_file.get(os.path.basename(src), [])
-        st = _stamp([src] + deps, " ".join(fl))
+        st = _stamp([src] + deps, " ".join(flags))
         stf = obj + ".stamp"
         objs.append(obj)
         if force or not os.path.exists(obj) or not os.path.exists(stf) or open(stf).read() != st:
-            jobs.append((src, obj, stf, st, fl))
+            jobs.append((src, obj, stf, st))
 
     def comp(j):
-        src, obj, stf, st, fl = j
-        _run([HIPCC] + fl + ["-c", src, "-o", obj])
+        src, obj, stf, st = j
+        _run([HIPCC] + flags + ["-c", src, "-o", obj])
         open(stf, "w").write(st)
         if verbose:
             print("compiled", os.path.basename(src))

@@ -1148,16 +1148,13 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
     if (PART == 2 && dynamic) {
         // dynamic claiming; the next claim is issued before the current strip is processed, so that the round trip of the atomic
         // (1-2 us) hides behind a strip's worth of loads and MFMAs (a wave over-claims once at the end: harmless)
-        // The claim's return value stays in lane 0's VGPR until the strip is done: a readfirstlane right behind the atomic (round 3) put an
-        // s_waitcnt vmcnt(0) in front of the strip's 16 loads, i.e. every strip paid the atomic's round trip AND the loads' latency one
-        // after the other; now the two are outstanding together and the scalar copy is taken behind a scheduling barrier.
-        auto claim_issue = [&]() {
+        auto claim = [&]() {
             int g = 0;
             if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
-            return g;
+            return __builtin_amdgcn_readfirstlane(g);
         };
-        for (int g = __builtin_amdgcn_readfirstlane(claim_issue()); g < S;) {
-            const int gn_v = claim_issue();
+        for (int g = claim(); g < S;) {
+            const int gn = claim();
             const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
             if (band) {
                 if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
@@ -1166,9 +1163,7 @@ __global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict_
                 if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
                 else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
             }
-            int gn_late = gn_v;
-            asm volatile("" : "+v"(gn_late) : : "memory");      // pins the first use of the claim behind the strip's stores (hipcc hoists a bare readfirstlane back to the atomic)
-            g = __builtin_amdgcn_readfirstlane(gn_late);
+            g = gn;
         }
         return;
     }
