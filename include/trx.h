@@ -101,10 +101,6 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
- *   GEMM (trx_gemm and every product inside the library)
- *   "gemm_dma"    1 = fp64 general tile fed by a direct-to-LDS ring (TRX_GEMM_DMA)   auto: off (measured equal)
- *   "gemm_xcd"    1 = general tile launched in XCD-aware order: the workgroups one XCD runs together take 8 x 8 neighbouring tiles of one
- *                       matrix (TRX_GEMM_XCD)                                            auto: off (not yet measured)
  *   Hessenberg reduction: TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
 int trx_tuning(const char* key, int value);
 

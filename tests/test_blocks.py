@@ -69,32 +69,6 @@ def test_gemm_register_staged_general_tile(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 2e-5)])
-@pytest.mark.parametrize("m,n,k,batch,opB", [(70, 131, 45, 16, 2), (600, 530, 33, 4, 0), (130, 1100, 20, 6, 0)])
-def test_gemm_xcd_aware_tile_order(backend, dtype, tol, m, n, k, batch, opB):
-    """Knob gemm_xcd: the general tile launched as a 1-D grid whose workgroups 8 q + c (the ones XCD c runs together) take the 8 x 8 tiles of one
-    supertile, supertiles counted over the whole batch -- a pure re-indexing: same product.  Shapes: several matrices with one partial
-    supertile each; more than one supertile per matrix in both directions with ragged edges; a wide matrix (17 tile columns)."""
-    be = get_backend(backend)
-    A = crand((batch, m, k), dtype)
-    B = crand((batch, k, n) if opB == 0 else (batch, n, k), dtype)
-    one, zero = np.array([1.0 + 0j], dtype=dtype), np.array([0j], dtype=dtype)
-    dA, dB = be.dev(A), be.dev(B)
-    dC = be.dev(np.full((batch, m, n), np.nan, dtype=dtype))
-    try:
-        assert be.lib.tuning(b"gemm_xcd", 1) == 0
-        rc = be.lib.gemm(dtcode(dtype), 0, opB, m, n, k, one.ctypes.data, be.ptr(dA), k, m * k, be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2],
-                         zero.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
-    finally:
-        be.lib.tuning(b"gemm_xcd", 0)
-    assert rc == 0
-    Bm = B if opB == 0 else B.conj().transpose(0, 2, 1)
-    ref = A.astype(np.complex128) @ Bm.astype(np.complex128)
-    got = be.host(dC)
-    assert np.isfinite(got).all() and np.abs(got - ref).max() / np.abs(ref).max() < tol
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-3)])
 @pytest.mark.parametrize("n,nrhs", [(5, 3), (32, 32), (33, 7), (97, 130), (150, 20), (290, 40), (530, 16)])
 def test_lu_solve(backend, dtype, tol, n, nrhs):

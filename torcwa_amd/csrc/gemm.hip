@@ -29,7 +29,7 @@ constexpr int plane_of(int extent, bool k_contig, int bk) { return k_contig ? ex
 template <class T, int OPA, int OPB, int WR, int NT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
-                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper, int xs, int ys, int nb) {
+                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
     constexpr int LDK = BK + 2;
     constexpr int WC = 4 / WR;                   // waves along N
     constexpr int BM = 16 * WR, BN = 16 * NT * WC;
@@ -39,21 +39,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     __shared__ T Ai[plane_of(BM, OPA == TRX_OP_N, BK)];
     __shared__ T Br[plane_of(BN, OPB != TRX_OP_N, BK)];
     __shared__ T Bi[plane_of(BN, OPB != TRX_OP_N, BK)];
-    // Tile of this workgroup.  Plain mapping: (blockIdx.x, blockIdx.y) = tile, blockIdx.z = matrix -- consecutive tiles go to different
-    // XCDs (workgroup L of a launch runs on XCD L % 8), so the 64 workgroups resident on one XCD hold 64 unrelated tiles and every operand
-    // panel is fetched from memory once per tile.  XCD-aware mapping (xs > 0, knob gemm_xcd, 1-D grid): the workgroups 8 q + c, q = 64 s ..
-    // 64 s + 63, which XCD c runs together, take the 8 x 8 tiles of ONE supertile (number 8 s + c, counted over the whole batch), so that
-    // a K slab of an A row panel or B column panel is fetched once per 8 tiles.
-    int b = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x;
-    if (xs > 0) {
-        const unsigned L = blockIdx.x, q = L >> 3;
-        const unsigned S = (q >> 6) * 8 + (L & 7), per = (unsigned)xs * ys;
-        b = (int)(S / per);
-        if (b >= nb) return;
-        const unsigned r = S - (unsigned)b * per, tt = q & 63;
-        ty = (int)(r / xs) * 8 + (int)(tt >> 3);
-        tx = (int)(r % xs) * 8 + (int)(tt & 7);
-    }
+    const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
     C += (long)b * sC;
@@ -62,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         m = d.m; n = d.n; k = d.k;
         A += d.offA; B += d.offB; C += d.offC;
     }
-    const int m0 = ty * BM, n0 = tx * BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= m || n0 >= n) return;
     if (b_upper && n0 + BN < k) k = n0 + BN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
     const int t = threadIdx.x;
@@ -351,8 +337,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(int m, int n, int k, c
 // 73.3 TF-equivalent at 1922^3 x 128, 79.5 vs 80.1 at 4096^3, 29.7 vs 29.9 layer-solves/s in the bench) -- neither the load latency nor the
 // LDS stores nor the second barrier is what holds the 3M product at ~76 % of the matrix-core peak in issued MFMAs.  Default: off.
 static int gemm_dma_env() { const char* e = getenv("TRX_GEMM_DMA"); return (e && atoi(e) == 1) ? 1 : 0; }
-static int gemm_xcd_env() { const char* e = getenv("TRX_GEMM_XCD"); return e ? atoi(e) : 0; }
-static int g_gemm_xcd = gemm_xcd_env();       // trx_tuning("gemm_xcd", 0 / 1): XCD-aware tile order of the general tile (TRX_GEMM_XCD)
 static int g_gemm_dma = gemm_dma_env();       // trx_tuning("gemm_dma", 0 / 1): fp64 general tile through the direct-to-LDS ring (TRX_GEMM_DMA)
 
 template <class T, int OPA, int OPB>
@@ -361,9 +345,9 @@ void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T
     // K-slab depth 16 everywhere.  A 32-deep slab for the general tile (half the barriers per flop, twice the prefetch distance) was
     // measured SLOWER on MI355X with the 3M product (70.9 vs 72.6 TF at 1922^3 x 128: 256 VGPRs, one spill); the template keeps it.
     if (shape == 1)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else if (shape == 2)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else {
         if constexpr (sizeof(T) == 8) {
             if (g_gemm_dma) {
@@ -377,14 +361,7 @@ void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T
                 return;
             }
         }
-        const int xs = cdiv_i(cdiv_i(n, 64), 8), ys = cdiv_i(cdiv_i(m, 64), 8);
-        const long nsuper = (long)batch * xs * ys;
-        if (g_gemm_xcd && !desc && nsuper >= 16 && nsuper < (1L << 21)) {
-            // 8 supertiles (one per XCD) x 64 tiles per group of 512 workgroups
-            TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3((unsigned)(cdiv_i(nsuper, 8) * 512)), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, xs, ys, batch);
-            return;
-        }
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, 0, 0, batch);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     }
 }
 
@@ -403,10 +380,8 @@ int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, 
 }  // namespace
 
 int gemm_set_knob(const char* key, int value) {
-    if (value < 0 || value > 1) return TRX_ERR_ARG;
-    if (std::string(key) == "gemm_dma") g_gemm_dma = value;
-    else if (std::string(key) == "gemm_xcd") g_gemm_xcd = value;
-    else return TRX_ERR_ARG;
+    if (std::string(key) != "gemm_dma" || value < 0 || value > 1) return TRX_ERR_ARG;
+    g_gemm_dma = value;
     return TRX_OK;
 }
 
