@@ -86,7 +86,6 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   "slab_dyn"    1 static / 2 dynamically claimed strips (TRX_SLAB_DYN)              auto: dynamic for groups of >= 16 matrices
  *   "slab_wgs"    32-4096 workgroups per dynamic off-window launch (TRX_SLAB_WGS)     auto: 512
  *   "slab_pipe"   2 = software-pipelined off-window kernel (TRX_SLAB_PIPE)            auto: off (measured slower)
- *   "qr_prio"     wave priority 1-3 (s_setprio) of the window-chase and AED kernels (TRX_QR_PRIO)   auto: 0 = default priority
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chain unitary
  *   Eigenvector route of trx_eig
  *   "eig_vec"     1 = all-fp64 pipeline with Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR

@@ -366,7 +366,6 @@ inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline void sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
 inline void sincosf(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
 inline void sincospi(double x, double* s, double* c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
-inline void __builtin_amdgcn_s_setprio(int) {}
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

@@ -124,7 +124,7 @@ def _set_knobs(be, **kw):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(eig_vec=2, qr_chains=2), dict(qr_prio=3)])
+@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(eig_vec=2, qr_chains=2)])
 def test_eig_tuning_knobs(backend, knobs):
     """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window, bulge chains per sweep; include/trx.h:
     trx_tuning) select different code paths, not results."""

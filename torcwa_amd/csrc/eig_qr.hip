@@ -44,13 +44,6 @@ constexpr int SM = 64;             // largest matrix the in-LDS single-wave rout
 constexpr int QAED = EigPlan::QAED;   // aggressive-early-deflation window
 constexpr int QAED_MOVES = 12;        // undeflatable eigenvalues moved out of the way per AED
 
-// s_setprio takes an immediate: 0 = leave the wave at the default priority
-__device__ __forceinline__ void wave_priority(int p) {
-    if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p == 3) __builtin_amdgcn_s_setprio(3);
-}
-
 template <class T>
 struct Rot {
     T c;
@@ -333,9 +326,8 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        int sm, int wantz, int prio, long long* dbg_all = nullptr) {
+                                                        int sm, int wantz, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
-    wave_priority(prio);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
     const int SLD = sm + 1;                                      // sm: largest small matrix of this launch (AED window = small-block threshold)
@@ -597,9 +589,8 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, int prio, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
-    wave_priority(prio);            // knob qr_prio: the 16 barrier-coupled waves of a chase against the slab-update waves sharing their CU
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
@@ -1333,7 +1324,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, prio = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1356,7 +1347,6 @@ static QrKnobs& qr_knobs() {
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
-        q.prio = geti("TRX_QR_PRIO", 0, 3, 0);                // wave priority (s_setprio) of the window-chase and AED kernels; 0 = leave the default
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1411,7 +1401,6 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
     else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
-    else if (s == "qr_prio") { slot = &k.prio; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1536,7 +1525,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
           TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz, K.prio,
+                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
                      (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
@@ -1554,8 +1543,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, K.prio, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, K.prio, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
             G.par ^= 1;
             { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
               // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
