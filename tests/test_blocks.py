@@ -288,3 +288,35 @@ def test_lu_row_split_singular_info(backend):
     finally:
         be.lib.tuning(b"lu_split", 0)
     assert be.host(info)[0] == 6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("where", ["first", "last"])
+def test_lu_row_split_nan_matrix_stays_in_bounds(backend, where):
+    """A NaN-filled matrix in the batch (what the mixed-precision eigensolver's refinement hands to lu_factor when the fp32 stage broke
+    down): no row passes the pivot search, the recorded pivots must still be rows of that matrix.  Before the fix piv[col] = n was
+    recorded and the interchange kernels swapped with row n: row 0 of the next matrix, or memory behind the last one (guard row here)."""
+    be = get_backend(backend)
+    n, nrhs, batch = 300, 3, 2
+    bad = 0 if where == "first" else batch - 1
+    A = crand((batch, n, n), np.complex128)
+    A[bad] = np.nan
+    B = crand((batch, n, nrhs), np.complex128)
+    flatA = np.concatenate([A.reshape(-1), np.full(n, 7.25 + 0j)])          # guard row behind the last matrix
+    flatB = np.concatenate([B.reshape(-1), np.full(nrhs, 7.25 + 0j)])
+    dA, dB = be.dev(flatA), be.dev(flatB)
+    piv, info = be.empty((batch, n), np.int32), be.empty((batch,), np.int32)
+    assert be.lib.tuning(b"lu_split", 128) == 0 and be.lib.tuning(b"lu_split_batch", 16) == 0
+    try:
+        assert be.lib.lu_solve(1, be.ptr(dA), n, be.ptr(dB), nrhs, batch, be.ptr(piv), be.ptr(info), be.stream) == 0
+    finally:
+        be.lib.tuning(b"lu_split", 0)
+        be.lib.tuning(b"lu_split_batch", 0)
+    hp, hi, hB, hA = be.host(piv), be.host(info), be.host(dB), be.host(dA)
+    assert hi[bad] != 0 and hi[1 - bad] == 0
+    assert (hp >= 0).all() and (hp < n).all()
+    assert (hA[batch * n * n:] == 7.25).all() and (hB[batch * n * nrhs:] == 7.25).all()
+    good = 1 - bad
+    X = np.linalg.solve(A[good], B[good])
+    Xg = hB[:batch * n * nrhs].reshape(batch, n, nrhs)[good]
+    assert np.abs(Xg - X).max() / np.abs(X).max() < 1e-10

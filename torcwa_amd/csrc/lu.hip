@@ -192,6 +192,17 @@ __global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ A
         }
         lu_best_reduce<T>(best, bi, red_v, red_i);
         if (t == 0) {
+            if (bi >= n) {
+                // no candidate at all: every remaining entry of the column failed `v > best` (NaN input).  Take the first row that is not
+                // chosen yet (one of k0 .. k0 + j is free), so that the recorded pivot is always a row of THIS matrix -- piv[col] = n would make
+                // the interchange kernels swap with row n, i.e. with the next matrix of the batch or past the buffer.  `best` stays -1:
+                // info is raised below as for a zero pivot.
+                for (int r = k0; r <= k0 + j; ++r) {
+                    bool used = false;
+                    for (int q = 0; q < j; ++q) used |= (piv[k0 + q] == r);
+                    if (!used) { bi = r; break; }
+                }
+            }
             s_p = bi;
             if (w == 0) {
                 piv[col] = bi;                            // chosen ROW (turned into an interchange by lu_split_final_kernel)
