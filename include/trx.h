@@ -70,9 +70,18 @@ int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* info, void*
 size_t trx_eig_ws_bytes(int dtype, int n, int batch);
 int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,
             void* stream);
+/* The same with PER-CALL options instead of the process-global knobs "eig_refine" / "eig_vec" (which remain the defaults of trx_eig):
+ *   opts bits 0-3: Newton steps of the mixed-precision route, 1-4 (0 = the knob's value);  bits 4-7: eigenvector route, 1-3 as knob "eig_vec"
+ *   (0 = the knob's value); other bits must be 0.  The options live only on the calling thread for the duration of the call, so solvers on
+ *   different host threads -- or a complex64 and a complex128 solver of one process -- cannot change each other's route or step count
+ *   (torcwa_amd.Engine.eig uses these entry points; tests/test_eig.py::test_eig_opts_two_threads).  The workspace size depends on the route:
+ *   size it with trx_eig_ws_bytes_opts and the SAME opts. */
+size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts);
+int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, void* stream, unsigned opts);
 
 /* Tuning knobs of libtrx (no reference counterpart).  Results do not depend on any of them (tests/test_eig.py, tests/test_blocks.py); they
- * select code paths.  Knobs are process-global and unsynchronised: trx_tuning must not race with a running trx_eig / trx_lu_solve.  The
+ * select code paths.  Knobs are process-global and unsynchronised: trx_tuning must not race with a running trx_eig / trx_lu_solve
+ * (per-call alternative for the eigensolver's route and refinement depth: trx_eig_opts).  The
  * environment variables named below are read ONCE per process as initial values.  Returns TRX_OK, or TRX_ERR_ARG for an unknown key or a
  * value out of range.  Unless stated otherwise value 0 = automatic (chosen from n and the batch size).
  *   QR phase of trx_eig
@@ -90,7 +99,8 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   Eigenvector route of trx_eig
  *   "eig_vec"     1 = all-fp64 pipeline with Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR
  *                       phase, 3 = mixed precision: fp32 eigendecomposition refined to fp64 by Newton steps (TRX_EIG_VEC)
- *                       auto: mixed precision for complex128 input of n >= 256, else Schur vectors; trx_eig_ws_bytes depends on this knob
+ *                       auto: mixed precision for complex128 input of n >= 256 AND batch >= 8, else Schur vectors; trx_eig_ws_bytes depends on
+ *                       this knob (per call and race-free: trx_eig_opts)
  *   "eig_refine"  1-4   Newton steps of the mixed-precision route; 0 = default (2: the accuracy class of the all-fp64 pipeline; one step
  *                       leaves an eigen-residual of ~5e-12 ||A||, which is what torcwa_amd asks for on behalf of complex64 problems)
  *   "invit_cfg"   0-6   layout of the inverse-iteration kernel (TRX_INVIT_CFG): 0/1 512 threads, register prefetch 2 deep; 2: 3 deep;

@@ -22,6 +22,13 @@ def run(m, n, k, batch, beta=0.0, reps=5):
     by = 16.0 * batch * (m * k + k * n + m * n * (2 if beta else 1))
     print(f"m={m:5d} n={n:5d} k={k:5d} batch={batch:3d} beta={beta}: {dtm*1e3:8.3f} ms  {fl/dtm/1e12:6.1f} TFLOP/s  {by/dtm/1e9:7.0f} GB/s(algorithmic)", flush=True)
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hot":          # the large fp64 shapes of the bench step
+        run(1922, 1922, 1922, 128)
+        run(1666, 1666, 256, 128, beta=1.0)                 # LU trailing update (outer block 256)
+        run(1922, 3844, 1922, 128)                          # 2n right-hand sides
+        run(961, 961, 961, 128)
+        run(4096, 4096, 4096, 4)
+        sys.exit(0)
     run(1922, 1922, 1922, 32)
     run(1922, 1922, 1922, 128)
     run(1922, 1922, 32, 128, beta=1.0)

@@ -46,6 +46,37 @@ def test_gemm(backend, dtype, tol, opA, opB, m, n, k, ring):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("opA,opB,m,n,k,beta", [
+    (0, 0, 2 * 160 + 2, 2 * 128 + 2, 77, 0.0),      # remainders of 2 rows / columns against every tile: peeled (cfg 1: 322 = 3 x 96 + 34, in-tile)
+    (0, 2, 2 * 128 + 40, 2 * 96 + 50, 64, 1.0),     # remainders above 32: ragged large tiles; beta != 0; K a multiple of the slab
+    (2, 0, 330, 259, 131, 1.0),                     # A conjugate-transposed; 17 slabs with a K tail of 3
+    (1, 1, 321, 270, 70, 0.0),
+])
+def test_gemm_large_tile(backend, cfg, opA, opB, m, n, k, beta):
+    """gemm_big.hip (knob gemm_big = tile configuration): one wave per SIMD, register-pinned accumulators, direct-to-LDS ring; against numpy,
+    with the thin-remainder peel of gemm.hip in play."""
+    be = get_backend(backend)
+    batch = 2
+    dtype = np.complex128
+    A = crand((batch, m, k) if opA == 0 else (batch, k, m), dtype)
+    B = crand((batch, k, n) if opB == 0 else (batch, n, k), dtype)
+    C0 = crand((batch, m, n), dtype)
+    al, bt = np.array([0.7 - 0.2j], dtype=dtype), np.array([beta * (-0.3 + 0.5j)], dtype=dtype)
+    dA, dB, dC = be.dev(A), be.dev(B), be.dev(C0)
+    try:
+        assert be.lib.tuning(b"gemm_big", cfg) == 0
+        rc = be.lib.gemm(1, opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
+                         be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
+    finally:
+        be.lib.tuning(b"gemm_big", 0)
+    assert rc == 0
+    f = {0: lambda x: x, 1: lambda x: x.transpose(0, 2, 1), 2: lambda x: x.conj().transpose(0, 2, 1)}
+    ref = al[0] * (f[opA](A) @ f[opB](B)) + bt[0] * C0
+    assert np.abs(be.host(dC) - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_gemm_register_staged_general_tile(backend):
     """Knob gemm_dma: the fp64 general tile through the direct-to-LDS ring (1) and through the register-staged kernel (0, the default:
     measured equally fast) give the same product."""

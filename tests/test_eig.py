@@ -350,3 +350,76 @@ def test_eig_two_host_threads_small_batches():
         th.join()
     assert not errors, errors
     assert max(worst) < 1e-12, worst
+
+
+def run_eig_opts(be, A, opts):
+    batch, n, _ = A.shape
+    dA = be.dev(A)
+    w, V = be.empty((batch, n), A.dtype), be.empty((batch, n, n), A.dtype)
+    info = be.dev(np.full((batch,), -1, dtype=np.int32))
+    nws = be.lib.eig_ws_bytes_opts(dtcode(A.dtype), n, batch, opts)
+    assert nws > 0
+    ws = be.empty((nws,), np.uint8)
+    assert be.lib.eig_opts(dtcode(A.dtype), be.ptr(dA), be.ptr(w), be.ptr(V), n, batch, be.ptr(info), be.ptr(ws), nws, be.stream, opts) == 0
+    return be.host(w), be.host(V), be.host(info)
+
+
+def _residual(A, w, V):
+    return max(np.abs(A[b] @ V[b] - V[b] * w[b][None, :]).max() / (np.abs(A[b]).max() * A.shape[1] ** 0.5) for b in range(A.shape[0]))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_opts_per_call(backend):
+    """trx_eig_opts: route and Newton steps of ONE call (bits 0-3 steps, bits 4-7 route), no process-global knob involved: the mixed route
+    with 1 step and with 2 steps give their own residual classes, the workspace size follows the route, invalid option words are refused,
+    and a plain trx_eig afterwards still runs the knobs' defaults (all-fp64 for this small batch)."""
+    be = get_backend(backend)
+    n = 70 if backend == "emu" else 400
+    A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex128)
+    mixed1, mixed2, schur = 1 | (3 << 4), 2 | (3 << 4), 1 << 4
+    r1 = _residual(A, *run_eig_opts(be, A, mixed1)[:2])
+    r2 = _residual(A, *run_eig_opts(be, A, mixed2)[:2])
+    rs = _residual(A, *run_eig_opts(be, A, schur)[:2])
+    assert 1e-12 < r1 < 3e-8 and r2 < 1e-13 and rs < 1e-13, (r1, r2, rs)
+    assert be.lib.eig_ws_bytes_opts(1, n, 2, mixed2) > be.lib.eig_ws_bytes_opts(1, n, 2, schur) == be.lib.eig_ws_bytes(1, n, 2)
+    assert be.lib.eig_ws_bytes_opts(1, n, 2, 5) == 0 and be.lib.eig_ws_bytes_opts(1, n, 2, 4 << 4) == 0 and be.lib.eig_ws_bytes_opts(1, n, 2, 1 << 8) == 0
+    w, V, info = run_eig(be, A)
+    check(A, w, V, info, 1e-13)
+
+
+@pytest.mark.gpu
+def test_eig_opts_two_threads():
+    """Two host threads in one process, one solving with the mixed route and ONE Newton step (what a complex64 user gets), the other with
+    THREE (complex128 / differentiable path), each on its own stream, through Engine.eig: every call must come out in the residual class
+    of its OWN step count.  With the process-global knob of round 3 (`trx_tuning("eig_refine")` before every call) the two overwrote each
+    other between the knob call and trx_eig."""
+    import threading
+    import torch
+    from torcwa_amd.engine import Engine
+    eng = Engine()
+    dev = eng.device
+    rng = np.random.default_rng(815)
+    n, batch = 300, 8                               # batch >= 8 and n >= 256: the automatic route is the mixed one
+    A = torch.from_numpy((rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))).astype(np.complex128)).to(dev)
+    errors, res = [], [[], []]
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                for _ in range(6):
+                    w, V = eng.eig(A, refine_steps=1 if t == 0 else 3)
+                    r = (torch.linalg.norm(A @ V - V * w[:, None, :], dim=(1, 2)) / torch.linalg.norm(A, dim=(1, 2))).max()
+                    res[t].append(float(r))
+                st.synchronize()
+        except BaseException as e:      # noqa: BLE001 - reported on the test's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert all(1e-12 < r < 1e-6 for r in res[0]), res[0]        # one step: first-order accurate in the fp32 start
+    assert all(r < 1e-13 for r in res[1]), res[1]               # three steps: the all-fp64 class

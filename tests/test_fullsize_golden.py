@@ -121,3 +121,36 @@ def test_oracle_pinned_at_full_size(name):
         for b, pol in enumerate(POLS):
             v = orc.s_parameters(s, S, ORDERS_PROBE, direction=dr, port=pt, polarization=pol).numpy()
             assert np.abs(v - g["sparams"][a, b]).max() / max(np.abs(g["sparams"][a, b]).max(), 1e-3) < 1e-9, (dr, pt, pol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("c64", 1e-5), ("c128", 1e-9)])
+def test_bench_code_path_config2_128_points(dtype, tol):
+    """The benchmarked code path itself against the reference: the 128-lambda sweep of configs[1] built by bench.py's
+    own `make_inputs`, solved as ONE chunk of 128 points by `solve_single_layer_sweep` exactly as `bench.run_step` does (library default
+    routes: 4 iteration groups in the QR phase, mixed-precision eigensolver, large-tile GEMM), and held against the reference fixtures of
+    the first and the last sweep point (lambda = 400 nm and 700 nm: `config2_o15_l400` / `config2_o15_l700`, the reference's loop of
+    example/Example1.ipynb:109-118 run in complex128 on the same complex64-representable inputs): every probe order of the forward
+    transmission, xx and yy."""
+    import bench
+    from tests.helpers import ORDERS_PROBE
+    from torcwa_amd.sweep import solve_single_layer_sweep
+    eng = make_engine("gpu")
+    freq, grids, lam, eps_si = bench.make_inputs(2, np.arange(128), 300, eng.device)
+    gl = [load_case("config2_o15_l400", "c128f32"), load_case("config2_o15_l700", "c128f32")]
+    for i, g in ((0, gl[0]), (127, gl[1])):          # the sweep's own inputs ARE the fixtures' inputs
+        assert abs(float(freq[i]) - float(g["freq"])) < 1e-15
+        assert np.abs(grids[i].cpu().numpy().astype(np.complex128) - g["L0_eps_grid"]).max() < 4e-6
+    cdt = torch.complex64 if dtype == "c64" else torch.complex128
+    # points 0 and 127 take the fixtures' grids bit for bit (float32-representable, so the cast to complex64 is exact): the gate carries no
+    # input slack; bench.py's own grids differ from them by one float32 rounding of the density (asserted above)
+    grids = grids.to(torch.complex128).clone()
+    grids[0] = torch.from_numpy(gl[0]["L0_eps_grid"]).to(eng.device)
+    grids[127] = torch.from_numpy(gl[1]["L0_eps_grid"]).to(eng.device)
+    for pol, pi in (("xx", 0), ("yy", 3)):
+        out = solve_single_layer_sweep(freq, grids.to(cdt), 300., [15, 15], [300., 300.], eps_in=1.46 ** 2, dtype=cdt, precision="high", engine=eng,
+                                       chunk=128, streams=1, check_info=False, orders=[tuple(o) for o in ORDERS_PROBE[:7]], polarization=pol).cpu().numpy()
+        assert out.shape == (128, 7) and np.isfinite(out).all()
+        for i, g in ((0, gl[0]), (127, gl[1])):
+            ref = g["sparams"][0, pi, :7]
+            assert np.abs(out[i] - ref).max() / np.abs(ref).max() < tol, (pol, i)

@@ -238,3 +238,38 @@ def test_homogeneous_layers_block_diagonal_path(backend, stack):
     for a, b, c in zip(*res):
         assert np.abs(a - b).max() < 1e-10
         assert np.abs(c - b).max() < 1e-10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fold_layers_with_differentiable_layer_behind_folded_ones(backend):
+    """fold_layers decides per layer: a plain layer is folded into the running cascade, a differentiable layer added AFTER it stays a
+    stored layer and solve_global_smatrix continues the cascade over it.  (The global early return of round 3 silently dropped every
+    layer behind the folded prefix: wrong S-parameters and gradients with no error.)  Same S-parameters and the same gradient as the
+    stored-layer path."""
+    import torcwa_amd
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(11)
+    B, order, L = 2, [2, 1], [310., 270.]
+    g0 = (1.0 + 4.0 * torch.rand(B, 14, 12, generator=gen, dtype=torch.float64)).to(eng.device)
+    g1 = (1.0 + 3.0 * torch.rand(B, 14, 12, generator=gen, dtype=torch.float64)).to(eng.device)
+    freq = torch.tensor([1 / 500., 1 / 590.], dtype=torch.float64)
+    out = []
+    for fold in (False, True):
+        rho = g1.clone().requires_grad_(True)
+        sim = torcwa_amd.BatchedRCWA(freq, order, L, dtype=torch.complex128, engine=eng, keep_coupling=False, fold_layers=fold)
+        sim.add_input_layer(eps=2.1)
+        sim.set_incident_angle(torch.tensor([0.1, 0.3], dtype=torch.float64), 0.2)
+        sim.add_layer(torch.tensor([80., 95.]), g0)          # plain: folded when fold_layers
+        sim.add_layer(35., 1.7)                              # plain, homogeneous: folded
+        sim.add_layer(torch.tensor([60., 70.]), rho)         # differentiable: must stay in the cascade
+        sim.add_layer(20., 2.2)                              # behind a stored layer: stored as well
+        sim.solve_global_smatrix()
+        t = sim.S_parameters([[0, 0]], polarization="xx")      # (an evanescent order would put the reference's own 0 * inf into the gradient)
+        fom = (t.abs() ** 2).sum()
+        fom.backward()
+        out.append((t.detach().cpu().numpy(), rho.grad.detach().cpu().numpy()))
+        if fold:
+            assert sim._n_folded == 2
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-10
+    assert np.abs(out[0][1]).max() > 0
+    assert np.abs(out[0][1] - out[1][1]).max() / np.abs(out[0][1]).max() < 1e-8

@@ -93,6 +93,7 @@ class BatchedRCWA:
         # of K (configs[2]: 4 layers at n = 3698).  The per-layer attributes of such a solver are None.
         self.fold_layers = bool(fold_layers) and not keep_coupling
         self._running = None
+        self._n_folded = 0            # layers 0 .. _n_folded-1 live in _running; the rest are stored layers
 
         if batch is None:
             batch = freq.numel() if (torch.is_tensor(freq) and freq.dim() > 0) else (len(freq) if isinstance(freq, (list, tuple)) else 1)
@@ -261,9 +262,13 @@ class BatchedRCWA:
         self._fold_last_layer()
 
     def _fold_last_layer(self):
-        if not self.fold_layers or getattr(self, "_diff", False):
-            return
+        """Streaming cascade: fold the layer just added into the running star product and drop it.  Decided PER LAYER: a layer is folded
+        only while the stack so far is a plain (non-differentiable) prefix 0 .. i-1 that has itself been folded; from the first
+        differentiable layer on, layers stay stored and solve_global_smatrix continues the cascade from the folded prefix over them
+        (a global early return here used to leave such layers out of the cascade altogether)."""
         i = self.layer_N - 1
+        if not self.fold_layers or getattr(self, "_diff", False) or self._n_folded != i:
+            return
         S = self._layer_S(i)
         if self._running is None:
             self._running = S
@@ -271,6 +276,7 @@ class BatchedRCWA:
             self._running, _ = self._star(self._running, S, [[], []], [[], []])
         self.layer_S11[i] = self.layer_S21[i] = None
         self.eps_conv[i] = None
+        self._n_folded = i + 1
 
     def _add_homogeneous_layer_bd(self, thickness, eps_s, mu_s):
         """Homogeneous layer without field bookkeeping (keep_coupling=False): every operator of rcwa.py:1206-1222 and 1244-1281
@@ -485,9 +491,9 @@ class BatchedRCWA:
     def solve_global_smatrix(self):                                                     # rcwa.py:173-211
         n, B = self.n, self.B
         self._zero_layer_S = False
-        folded = self.fold_layers and self._running is not None
-        if folded:
-            S, C = self._running, [[], []]
+        first = 1                                                                       # first stored layer still to be folded in
+        if self._n_folded > 0:
+            S, C, first = self._running, [[], []], self._n_folded
         elif self.layer_N > 0:
             S = self._layer_S(0)
             C = self._layer_C(0)
@@ -497,7 +503,7 @@ class BatchedRCWA:
             S = [I, Z, Z.clone(), I.clone()]
             C = [[], []]
             self._zero_layer_S = not (self.has_in or self.has_out)     # reference stores 1-D zeros (rcwa.py:187-188)
-        for i in range(1, 0 if folded else self.layer_N):
+        for i in range(first, self.layer_N):
             S, C = self._star(S, self._layer_S(i), C, self._layer_C(i))
         if self.has_in:                                                                 # rcwa.py:198-202
             S, C = self._star(self._Sin, S, [[], []], C)

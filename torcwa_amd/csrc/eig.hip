@@ -17,11 +17,20 @@ static int eig_vec_env() {
     return (v >= 0 && v <= 3) ? v : 0;
 }
 static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
-bool eig_uses_invit(int n) { return g_eig_vec == 2 && n <= INVIT_NMAX && n >= 2; }
+// Per-call options (trx_eig_opts / trx_eig_ws_bytes_opts): route and Newton steps of THIS call, held thread-locally for the duration of the
+// call on the calling host thread -- the process-global knobs are only the defaults, so two threads (or a complex64 and a complex128 solver
+// in one process) can no longer overwrite each other's setting between trx_tuning and trx_eig.  -1 = not set (use the knob).
+static thread_local int tl_eig_vec = -1, tl_refine = -1;
+static inline int cur_eig_vec() { return tl_eig_vec >= 0 ? tl_eig_vec : g_eig_vec; }
+struct EigCallOpts {
+    EigCallOpts(unsigned opts) { const int r = opts & 0xF, v = (opts >> 4) & 0xF; tl_refine = r ? r : -1; tl_eig_vec = v ? v : -1; }
+    ~EigCallOpts() { tl_refine = -1; tl_eig_vec = -1; }
+};
+bool eig_uses_invit(int n) { return cur_eig_vec() == 2 && n <= INVIT_NMAX && n >= 2; }
 // mixed-precision route (fp32 eigendecomposition + Newton refinement in fp64, eig_refine.hip): fp64 problems of at least 256 rows
 // Automatic: batches of at least 8 (measured, n = 1922: +6 % of the whole layer-solve step at batch 16, 64 and 128; a single n = 5202
 // matrix, whose fp64 solve is a latency chain that fp32 does not shorten, loses 60 % to the extra refinement work).
-bool eig_uses_mixed(int n, int batch, size_t elem) { return elem == 8 && ((g_eig_vec == 3 && n >= 8) || (g_eig_vec == 0 && n >= 256 && batch >= 8)); }
+bool eig_uses_mixed(int n, int batch, size_t elem) { return elem == 8 && ((cur_eig_vec() == 3 && n >= 8) || (cur_eig_vec() == 0 && n >= 256 && batch >= 8)); }
 int eig_set_knob(const char* key, int value) {
     if (std::string(key) != "eig_vec" || value < 0 || value > 3) return TRX_ERR_ARG;
     g_eig_vec = value;
@@ -173,7 +182,7 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
             int any = 0;
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
-            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, refine_steps(), &any);
+            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any);
             if (rc) return rc;
             if (!any) return finish_vectors<T>(s, B, n, batch, (cx<T>*)V);
             // some matrix has a cluster of more than two eigenvalues, an fp32 result that is too far off, or a singular V: redo the batch
@@ -295,6 +304,18 @@ extern "C" int trx_tuning(const char* key, int value) {
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {
     if (n <= 0 || batch <= 0) return 0;
     return dtype == TRX_C128 ? trx::eig_ws_bytes_t<double>(n, batch) : trx::eig_ws_bytes_t<float>(n, batch);
+}
+
+extern "C" size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts) {
+    if ((opts & 0xF) > 4 || ((opts >> 4) & 0xF) > 3 || (opts >> 8)) return 0;
+    trx::EigCallOpts guard(opts);
+    return trx_eig_ws_bytes(dtype, n, batch);
+}
+
+extern "C" int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, void* stream, unsigned opts) {
+    if ((opts & 0xF) > 4 || ((opts >> 4) & 0xF) > 3 || (opts >> 8)) return TRX_ERR_ARG;
+    trx::EigCallOpts guard(opts);
+    return trx_eig(dtype, A, w, V, n, batch, info, ws, ws_bytes, stream);
 }
 
 extern "C" int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes,

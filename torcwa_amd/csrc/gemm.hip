@@ -337,6 +337,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(int m, int n, int k, c
 // 73.3 TF-equivalent at 1922^3 x 128, 79.5 vs 80.1 at 4096^3, 29.7 vs 29.9 layer-solves/s in the bench) -- neither the load latency nor the
 // LDS stores nor the second barrier is what holds the 3M product at ~76 % of the matrix-core peak in issued MFMAs.  Default: off.
 static int gemm_dma_env() { const char* e = getenv("TRX_GEMM_DMA"); return (e && atoi(e) == 1) ? 1 : 0; }
+static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); return e ? atoi(e) : 0; }
+static int g_gemm_big = gemm_big_env();       // trx_tuning("gemm_big", 0 .. 3): large-tile fp64 kernel of gemm_big.hip (0 = off; tile configuration)
 static int g_gemm_dma = gemm_dma_env();       // trx_tuning("gemm_dma", 0 / 1): fp64 general tile through the direct-to-LDS ring (TRX_GEMM_DMA)
 
 template <class T, int OPA, int OPB>
@@ -380,10 +382,19 @@ int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, 
 }  // namespace
 
 int gemm_set_knob(const char* key, int value) {
+    if (std::string(key) == "gemm_big") {
+        if (value < 0 || value > 3) return TRX_ERR_ARG;
+        g_gemm_big = value;
+        return TRX_OK;
+    }
     if (std::string(key) != "gemm_dma" || value < 0 || value > 1) return TRX_ERR_ARG;
     g_gemm_dma = value;
     return TRX_OK;
 }
+
+template <class T>
+int launch_dispatch(hipStream_t s, int opA, int opB, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
+                    const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc = nullptr, int b_upper = 0);
 
 template <class T>
 int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
@@ -403,6 +414,36 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
     const bool nn = opA == TRX_OP_N && opB == TRX_OP_N;
     ProfScope prof(sizeof(T) == 8 ? (nn ? PROF_GEMM_NN : PROF_GEMM_OTHER) : (nn ? PROF_GEMM_NN_F32 : PROF_GEMM_OTHER_F32), s, desc ? 0.0 : 8.0 * macs,
                    desc ? 0.0 : el * ((double)m * k + (double)k * n + (double)m * n * ((beta.x != T(0) || beta.y != T(0)) ? 2 : 1)));
+    if constexpr (sizeof(T) == 8) {
+        // Large-tile kernel (gemm_big.hip) for large fp64 outputs.  A thin remainder (at most 32 rows / columns beyond a multiple of the
+        // block tile: 1922 = 15 x 128 + 2 = 20 x 96 + 2) is peeled off for the flat / narrow tiles of this file instead of costing a
+        // whole row / column of almost empty large tiles.
+        int bm = 0, bn = 0;
+        if (g_gemm_big) gemm_big_tile(g_gemm_big, &bm, &bn);
+        if (g_gemm_big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64) {
+            const int rm = (m % bm) <= 32 ? m % bm : 0, rn = (n % bn) <= 32 ? n % bn : 0;
+            const int mm = m - rm, nm = n - rn;
+            int rc = gemm_big(s, g_gemm_big, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);
+            if (rc != TRX_OK) return rc;
+            if (rm) {      // bottom rows, all columns
+                const cx<T>* Ar = A + (opA == TRX_OP_N ? (long)mm * lda : (long)mm);
+                rc = launch_dispatch<T>(s, opA, opB, 2, batch, rm, n, k, alpha, Ar, lda, sA, B, ldb, sB, beta, C + (long)mm * ldc, ldc, sC);
+                if (rc != TRX_OK) return rc;
+            }
+            if (rn) {      // right columns of the rows above
+                const cx<T>* Bc = B + (opB == TRX_OP_N ? (long)nm : (long)nm * ldb);
+                rc = launch_dispatch<T>(s, opA, opB, 1, batch, mm, rn, k, alpha, A, lda, sA, Bc, ldb, sB, beta, C + nm, ldc, sC);
+                if (rc != TRX_OK) return rc;
+            }
+            return TRX_OK;
+        }
+    }
+    return launch_dispatch<T>(s, opA, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
+}
+
+template <class T>
+int launch_dispatch(hipStream_t s, int opA, int opB, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
+                    const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
     switch (opA) {
         case TRX_OP_N: return launch_b<T, TRX_OP_N>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
         case TRX_OP_T: return launch_b<T, TRX_OP_T>(s, opB, shape, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);

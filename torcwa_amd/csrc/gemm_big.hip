@@ -1,0 +1,306 @@
+// Large-tile complex128 GEMM for the square products of the hot path (refinement, S-matrix stage, LU trailing updates; the call sites of
+// gemm.hip): C = alpha op(A) op(B) + beta C with a 128 x 96 block tile, ONE wave per SIMD.
+//
+// Why a second kernel.  The 64 x 64 tile of gemm.hip moves 32 KB of operands per 64 x 64 x 16 complex MACs (16 flop/B in the 8-flops-per-MAC
+// count) and measured 73-74 TF-equivalent on 1922^3 x 128 however its operands arrive (register-staged, direct-to-LDS ring, true prefetch:
+// profiles/r03_gemm_ring.txt, profiles/r04_ab/r4_ab_chain.txt), with 17x the algorithmic bytes crossing the L2 -> fabric boundary (PMC).
+// A tile has to be larger to need fewer bytes per flop, and the 3M product needs three accumulators per 16 x 16 output tile (24 registers),
+// so a larger tile does not fit next to a second wave on the SIMD.  Here a workgroup is 4 waves = one per SIMD, each wave owns 64 x 48
+// (4 x 3 MFMA tiles = 288 accumulator registers of the SIMD's 512), and what the second wave used to hide is hidden by the wave itself:
+//   * operands arrive by global_load_lds_dwordx4 into a ring of GST stages of GBK k-values, GST - 1 slabs ahead: no staging registers, no
+//     LDS stores, loads in flight across barriers;
+//   * fragments are double-buffered in registers: the ds_read_b128 of k-step s + 1 are issued in front of the 36 MFMAs of k-step s;
+//   * ONE barrier per slab, placed in the MIDDLE of the slab (it publishes slab s + 1 and frees the stage of slab s - 1), so the first
+//     fragments of the next slab are read under the MFMAs of the current one and no LDS latency is exposed at a slab boundary.
+// Bytes per flop: (128 + 96) x 16 B per 128 x 96 complex MACs and k-value = 27.4 flop/B (the 64 x 64 tile: 16).
+//
+// LDS layouts (interleaved complex, one element = one lane of a direct load; bank conflicts of the b128 fragment reads checked by brute
+// force over the hardware's 16-lane groups):
+//   operand whose k index is contiguous in memory (A of op N, B of op T / C):  [major][GBK + 2]  (row stride 10 elements: conflict-free;
+//                                                                             a lane group of a load covers 8 consecutive k of 2 rows)
+//   operand whose major index is contiguous (A of op T / C, B of op N):       [GBK][major]       (conflict-free for any multiple of 16)
+// K tail: clamped loads read finite data, the A fragment is masked.  Rows / columns beyond the matrix: clamped loads, guarded stores; a
+// wave whose 64 x 48 part lies entirely outside issues no MFMAs.
+#include "mfma.hpp"
+#include "prof.hpp"
+
+#include <cstdlib>
+#include <utility>
+
+namespace trx {
+namespace {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body (the register-pinned
+// accumulator macros print it into the instruction text)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+constexpr int QBK = 8, QST = 4;             // k-values per slab, ring stages
+constexpr int QP = QBK + 2;                 // row stride of a k-contiguous operand in LDS (elements)
+
+// WM waves along M (4 / WM along N), QTM x QTN MFMA tiles (16 x 16) per wave
+template <int OPA, int OPB, int WM, int WN, int QTM, int QTN>
+struct BigCfg {
+    static constexpr int NW = WM * WN;                                                             // waves of a workgroup
+    static constexpr int QBM = 16 * QTM * WM, QBN = 16 * QTN * WN;                          // block tile
+    static constexpr bool A_KC = (OPA == TRX_OP_N), B_KC = (OPB != TRX_OP_N);
+    static constexpr int SA = A_KC ? QBM * QP : QBK * QBM, SB = B_KC ? QBN * QP : QBK * QBN;      // slots of the A / B part of a stage
+    static constexpr int CA = (SA + 63) / 64, CB = (SB + 63) / 64;                                 // 64-slot chunks = wave-wide loads
+    static constexpr int NI = (CA + CB + NW - 1) / NW;                                                   // loads per wave and slab
+    static constexpr int STG = (CA + CB) * 64;                                                     // stage, in elements
+    static constexpr size_t smem = sizeof(cx<double>) * ((size_t)QST * STG + 64);                  // + one scratch chunk for padding loads
+};
+
+// PIN: accumulators pinned to AGPRs (one wave per SIMD, up to 256 accumulator registers); otherwise ordinary values, for the 8-wave
+// layouts whose 144 accumulator registers fit the VGPR form of the MFMA next to a second wave on the SIMD
+template <int OPA, int OPB, int WM, int WN, int QTM, int QTN, bool PIN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(int m, int n, int k, cx<double> alpha, const cx<double>* __restrict__ A, int lda, long sA,
+                                                      const cx<double>* __restrict__ B, int ldb, long sB, cx<double> beta, cx<double>* __restrict__ C,
+                                                      int ldc, long sC, int b_upper) {
+    typedef double T;
+    typedef BigCfg<OPA, OPB, WM, WN, QTM, QTN> Cfg;
+    constexpr int QBM = Cfg::QBM, QBN = Cfg::QBN, NW = Cfg::NW;
+    constexpr bool A_KC = Cfg::A_KC, B_KC = Cfg::B_KC;
+    constexpr int CA = Cfg::CA, CB = Cfg::CB, NI = Cfg::NI, STG = Cfg::STG;
+    TRX_DYN_SMEM(smem);
+    cx<T>* ring = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* scratch = ring + QST * STG;
+    const int b = blockIdx.z;
+    A += (long)b * sA;
+    B += (long)b * sB;
+    C += (long)b * sC;
+    const int m0 = blockIdx.y * QBM, n0 = blockIdx.x * QBN;
+    if (b_upper && n0 + QBN < k) k = n0 + QBN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+
+    // ---- what this lane fetches: chunks wave, wave + 4, ... of a stage; the element follows from the LDS slot p = 64 c' + lane
+    const cx<T>* gsrc[NI];        // address of the lane's element at k = 0 (clamped row / column)
+    int gkk[NI];                  // its k offset inside a slab (pad slots and padding loads re-read offset 0)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = wave + NW * i;
+        if (c < CA) {
+            const int p = 64 * c + lane;
+            int row, kk;
+            if (A_KC) { row = p / QP; kk = p - row * QP; } else { kk = p / QBM; row = p - kk * QBM; }
+            if (row >= QBM) row = QBM - 1;
+            if (kk >= QBK) kk = 0;
+            const int gr = m0 + row < m ? m0 + row : m - 1;
+            gsrc[i] = A_KC ? A + (long)gr * lda : A + gr;
+            gkk[i] = kk;
+        } else if (c < CA + CB) {
+            const int p = 64 * (c - CA) + lane;
+            int col, kk;
+            if (B_KC) { col = p / QP; kk = p - col * QP; } else { kk = p / QBN; col = p - kk * QBN; }
+            if (col >= QBN) col = QBN - 1;
+            if (kk >= QBK) kk = 0;
+            const int gc = n0 + col < n ? n0 + col : n - 1;
+            gsrc[i] = B_KC ? B + (long)gc * ldb : B + gc;
+            gkk[i] = kk;
+        } else {
+            gsrc[i] = A; gkk[i] = 0;
+        }
+    }
+    const int arow0 = 16 * QTM * (wave % WM), bcol0 = 16 * QTN * (wave / WM);
+    const int lr = lane & 15, lk = lane >> 4;
+    const bool active = (m0 + arow0 < m) && (n0 + bcol0 < n);                // wave-uniform: anything of this wave's 64 x 48 inside?
+    const int nslab = (k + QBK - 1) / QBK;
+    // fragment slots inside a stage (k-step 0)
+    const int aslot = A_KC ? (arow0 + lr) * QP + lk : lk * QBM + arow0 + lr;
+    const int bslot = CA * 64 + (B_KC ? (bcol0 + lr) * QP + lk : lk * QBN + bcol0 + lr);
+    constexpr int a_i = A_KC ? 16 * QP : 16, a_k = A_KC ? 4 : 4 * QBM;      // slot steps per row tile / per k-step
+    constexpr int b_j = B_KC ? 16 * QP : 16, b_k = B_KC ? 4 : 4 * QBN;
+
+    // ---- main loop.  One wave per SIMD: nothing hides a latency unless the wave's own instruction order does, so the order is written
+    // down slot by slot and pinned (sched_barrier): a slot is ONE MFMA (64 cycles of the matrix pipe) plus at most one cheap side operation
+    // that issues in its shadow.  A slab is two k-steps = 2 x NMF slots:
+    //   k-step 0 (fragment set 0)   slots 0 .. NF-1        ds_read_b128 of the fragments of k-step 1 (set 1)
+    //                               slot  NF+1             s_waitcnt vmcnt (own loads of slab s+1 landed) + s_barrier: publishes slab s+1
+    //                                                      and frees the stage of slab s-1 (its last reader passed a barrier since)
+    //                               slots NF+2 .. +NI-1    direct-to-LDS loads of slab s+3 into that stage
+    //                               then NF slots          finish set 1 (K-tail mask, conjugation, 3M sum)
+    //   k-step 1 (fragment set 1)   slots 0 .. NF-1        ds_read_b128 of k-step 0 of slab s+1 (set 0);  slots NF+2 ..  finish set 0
+    // The barrier sits between two MFMAs of the same k-step: the pipe keeps running through it as long as the waves' skew stays below a slot.
+    constexpr int NF = QTM + QTN, NMF = 3 * QTM * QTN;
+    static_assert(NF + 2 + NI + NF <= NMF, "side operations of a k-step must fit its MFMA slots");
+    cx<T> ra[2][QTM], rb[2][QTN];                                            // raw fragments as read from LDS
+    T fa[2][QTM][3], fb[2][QTN][3];                                          // finished fragments: (re, im, re + im)
+    auto frag_read = [&](int set, int f, const cx<T>* st, int ks) __attribute__((always_inline)) {
+        if (f < QTM) ra[set][f] = st[aslot + f * a_i + ks * a_k];
+        else rb[set][f - QTM] = st[bslot + (f - QTM) * b_j + ks * b_k];
+    };
+    auto frag_finish = [&](int set, int f, bool kin) __attribute__((always_inline)) {
+        if (f < QTM) {
+            const T ar = kin ? ra[set][f].x : T(0);
+            T ai = kin ? ra[set][f].y : T(0);
+            if (OPA == TRX_OP_C) ai = -ai;
+            fa[set][f][0] = ar; fa[set][f][1] = ai; fa[set][f][2] = ar + ai;
+        } else {
+            const T br = rb[set][f - QTM].x, bi = (OPB == TRX_OP_C) ? -rb[set][f - QTM].y : rb[set][f - QTM].y;
+            fb[set][f - QTM][0] = br; fb[set][f - QTM][1] = bi; fb[set][f - QTM][2] = br + bi;
+        }
+    };
+    auto issue_one = [&](int i, int slab) __attribute__((always_inline)) {
+        const int c = wave + NW * i;                                          // wave-uniform
+        const int kg = slab * QBK + gkk[i] < k ? slab * QBK + gkk[i] : k - 1; // clamped: finite data, masked at the A fragment
+        const long step = c < CA ? (A_KC ? 1 : lda) : (c < CA + CB ? (B_KC ? 1 : ldb) : 0);       // padding load: re-reads A[0]
+        cx<T>* dst = c < CA + CB ? ring + (slab % QST) * STG + 64 * c : scratch;
+        TRX_LDS_DMA16(gsrc[i] + (long)kg * step, dst);
+    };
+#pragma unroll
+    for (int sl = 0; sl < QST - 1; ++sl)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_one(i, sl);                        // slabs beyond the last re-read the last k-value: never used
+    TRX_WAIT_VMCNT_IMM(2 * NI);                                               // slab 0 has landed: only the two younger slabs are in flight
+    __builtin_amdgcn_s_barrier();
+    if (!active) {
+        // a wave with nothing to compute still feeds the ring and meets the barriers
+        for (int sl = 0; sl < nslab; ++sl) {
+            TRX_WAIT_VMCNT_IMM(NI);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue_one(i, sl + QST - 1);
+        }
+        TRX_WAIT_VMCNT(0);
+        return;
+    }
+    // accumulators: P1, P2, P3 of MFMA tile (i, j) are the pinned accumulators 3 (i QTN + j) + 0 / 1 / 2 (common.hpp)
+    TRX_ACC_DECL(NMF);
+    typename Mfma<T>::acc_t pacc[PIN ? 1 : NMF];
+    static_for<NMF>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (PIN) TRX_ACC_ZERO(q);
+        else pacc[q] = typename Mfma<T>::acc_t{T(0), T(0), T(0), T(0)};
+    });
+    auto mfma_one = [&](int set, auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, tile = q / 3, part = q % 3, i = tile / QTN, j = tile % QTN;
+        const T av = fa[set][i][part], bv = fb[set][j][part];         // (locals: an asm operand alone does not capture in a generic lambda)
+        if constexpr (PIN) TRX_ACC_MFMA(q, av, bv);
+        else pacc[q] = Mfma<T>::mma(av, bv, pacc[q]);
+    };
+    {
+        const cx<T>* st = ring;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) frag_read(0, f, st, 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) frag_finish(0, f, lk < k);
+    }
+    for (int sl = 0; sl < nslab; ++sl) {
+        const cx<T>* st = ring + (sl % QST) * STG;
+        const cx<T>* stn = ring + ((sl + 1) % QST) * STG;
+        const bool kin1 = sl * QBK + 4 + lk < k, kin0 = (sl + 1) * QBK + lk < k;
+        static_for<NMF>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if (q < NF) frag_read(1, q, st, 1);
+            else if (q == NF + 1) { TRX_WAIT_VMCNT_IMM(NI); __builtin_amdgcn_s_barrier(); }
+            else if (q >= NF + 2 && q < NF + 2 + NI) issue_one(q - NF - 2, sl + QST - 1);
+            else if (q >= NF + 2 + NI && q < NF + 2 + NI + NF) frag_finish(1, q - NF - 2 - NI, kin1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_one(0, qc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<NMF>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if (q < NF) frag_read(0, q, stn, 0);
+            else if (q >= NF + 2 && q < NF + 2 + NF) frag_finish(0, q - NF - 2, kin0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_one(1, qc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    TRX_WAIT_VMCNT(0);                                                        // no direct-to-LDS load may outlive the workgroup's LDS allocation
+    if constexpr (PIN) TRX_ACC_DRAIN();                                      // the last MFMAs have written their accumulators
+
+    // ---- epilogue: C = alpha (P1 - P2, P3 - P1 - P2) + beta C, one row tile at a time (12 C elements per lane in flight)
+    const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
+    static_for<QTM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        cx<T> cv[4][QTN];
+        if (has_beta) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + arow0 + 16 * i + Mfma<T>::crow(lane, r);
+                const int rc = row < m ? row : m - 1;
+#pragma unroll
+                for (int j = 0; j < QTN; ++j) {
+                    const int col = n0 + bcol0 + 16 * j + lr;
+                    cv[r][j] = C[(long)rc * ldc + (col < n ? col : n - 1)];
+                }
+            }
+        }
+        static_for<4 * QTN>([&](auto rjc) {
+            constexpr int r = decltype(rjc)::value / QTN, j = decltype(rjc)::value % QTN;
+            const int row = m0 + arow0 + 16 * i + Mfma<T>::crow(lane, r), col = n0 + bcol0 + 16 * j + lr;
+            T a1, a2, a3;
+            if constexpr (PIN) {
+                TRX_ACC_READ(3 * (i * QTN + j), r, a1);
+                TRX_ACC_READ(3 * (i * QTN + j) + 1, r, a2);
+                TRX_ACC_READ(3 * (i * QTN + j) + 2, r, a3);
+            } else {
+                a1 = pacc[3 * (i * QTN + j)][r]; a2 = pacc[3 * (i * QTN + j) + 1][r]; a3 = pacc[3 * (i * QTN + j) + 2][r];
+            }
+            cx<T> v = alpha * cx<T>(a1 - a2, a3 - a1 - a2);
+            if (has_beta) v += beta * cv[r][j];
+            if (row < m && col < n) C[(long)row * ldc + col] = v;
+        });
+    });
+}
+
+template <int OPA, int OPB, int WM, int WN, int QTM, int QTN, bool PIN>
+int launch_big(hipStream_t s, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb, long sB,
+               cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
+    typedef BigCfg<OPA, OPB, WM, WN, QTM, QTN> Cfg;
+    static bool attr_done = false;       // > 64 KB of dynamic LDS: opt in once per instantiation
+    if (!attr_done) { (void)set_max_dyn_smem((const void*)gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN, PIN>, Cfg::smem); attr_done = true; }
+    TRX_LAUNCH((gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN, PIN>), dim3(cdiv_i(n, Cfg::QBN), cdiv_i(m, Cfg::QBM), batch), dim3(64 * Cfg::NW), Cfg::smem, s, m, n, k, alpha,
+               A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template <int OPA, int OPB>
+int launch_big_cfg(hipStream_t s, int cfg, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
+                   long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
+    switch (cfg) {
+        // one wave per SIMD, accumulators pinned to AGPRs
+        case 1: return launch_big<OPA, OPB, 2, 2, 3, 3, true>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);     //  96 x 96
+        case 2: return launch_big<OPA, OPB, 4, 1, 2, 5, true>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);     // 128 x 80
+        // two waves per SIMD (8-wave workgroup), accumulators in VGPRs: the partner wave covers load issue, barrier skew and LDS latency
+        case 3: return launch_big<OPA, OPB, 4, 2, 2, 3, false>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);    // 128 x 96
+        default: return TRX_ERR_ARG;
+    }
+}
+
+template <int OPA>
+int launch_big_b(hipStream_t s, int cfg, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
+                 long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
+    switch (opB) {
+        case TRX_OP_N: return launch_big_cfg<OPA, TRX_OP_N>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_T: return launch_big_cfg<OPA, TRX_OP_T>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_C: return launch_big_cfg<OPA, TRX_OP_C>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        default: return TRX_ERR_ARG;
+    }
+}
+}  // namespace
+
+void gemm_big_tile(int cfg, int* bm, int* bn) {
+    static const int t[4][2] = {{0, 0}, {96, 96}, {128, 80}, {128, 96}};
+    *bm = t[cfg][0]; *bn = t[cfg][1];
+}
+
+// The large-tile kernel (tile configuration cfg = 1 .. 3) on the whole m x n output (ragged edges by clamped loads and guarded stores).  The
+// caller (gemm.hip) decides when it pays and peels thin remainders off for the narrow tiles.
+int gemm_big(hipStream_t s, int cfg, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
+             int ldb, long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
+    switch (opA) {
+        case TRX_OP_N: return launch_big_b<TRX_OP_N>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_T: return launch_big_b<TRX_OP_T>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_C: return launch_big_b<TRX_OP_C>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        default: return TRX_ERR_ARG;
+    }
+}
+
+}  // namespace trx

@@ -150,16 +150,16 @@ class Engine:
         MI355X, one step is NOT enough for the 1e-5 gate of a complex64 problem at order [15,15] -- the fp32 start of this pipeline leaves
         max |E| ~ 2e-2 ... 2e-1 there)."""
         self._check(A)
-        self.lib.check(self.lib.tuning(b"eig_refine", int(refine_steps)))
+        opts = int(refine_steps) & 0xF          # per-call option word of trx_eig_opts (no process-global knob is touched: thread-safe)
         A = self._c(A) if destroy else A.clone()
         B, n, _ = A.shape
         dt = A.dtype
         w = torch.empty((B, n), dtype=dt, device=self.device)
         V = torch.empty((B, n, n), dtype=dt, device=self.device)
         info = self._ints(B)
-        nws = self.lib.eig_ws_bytes(_CODE[dt], n, B)
+        nws = self.lib.eig_ws_bytes_opts(_CODE[dt], n, B, opts)
         ws = self._ws(nws)
-        self.lib.check(self.lib.eig(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream))
+        self.lib.check(self.lib.eig_opts(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream, opts))
         self._info(info, "eig")
         return w, V
 
