@@ -107,6 +107,10 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       3: 1 deep; 4: 1024 threads; 5 / 6: 1024 / 512 threads with the direct-to-LDS column ring
  *   "invit_ring"  1-3 (register variants) or 3-4 (ring variants) columns of H resident in LDS;  "invit_wpl" 1, 2, 4, 8: minimum waves
  *                       per eigenvalue (tests);  "invit_xcd" 1 = plain 2-D grid instead of the XCD-aware launches;  "invit_dbg": timing experiments
+ *   GEMM (trx_gemm and every product inside the library)
+ *   "gemm_big"    large-tile complex128 kernel for outputs of at least 2 x 2 of its tiles and k >= 64 (TRX_GEMM_BIG): 1 = 96 x 96 and 2 = 128 x 80
+ *                       with one wave per SIMD, 3 = 128 x 96 with 8 waves, 4 = off (64 x 64 tile)                    auto: 3
+ *   "gemm_dma"    1 = the 64 x 64 tile through a direct-to-LDS operand ring (TRX_GEMM_DMA)                          auto: off (measured equal)
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch

@@ -301,8 +301,9 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
     for LU, Xg, piv in res:
         assert np.abs(Xg - X).max() / np.abs(X).max() < tol
     assert (res[0][2] == res[1][2]).all()
-    # same pivots, so the factors agree to rounding: fp32 reductions in another order differ by a few n eps (1.6e-5 measured at n = 300)
-    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < (1e-13 if dtype == np.complex128 else 1e-4)
+    # same pivots, so the factors agree to rounding: reductions in another order differ by a few n eps (fp32: 1.6e-5 measured at n = 300;
+    # fp64: 1.06e-13 at n = 530 on MI355X -- the test data depend on the RNG position, i.e. on the tests that ran before)
+    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < (1e-12 if dtype == np.complex128 else 1e-4)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

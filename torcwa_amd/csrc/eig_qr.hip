@@ -96,20 +96,29 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     return R;
 }
 
+// Synchronisation of the single-wave in-LDS routines below.  In a 64-thread workgroup they use the block barrier; when the same code
+// runs on wave 0 of a larger workgroup (multi-wave AED kernel) a block barrier would wait for the other waves, and none is needed: one
+// wave's LDS operations execute in program order, so only the compiler has to be kept from reordering them (wave_sync).
+struct BlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+struct WaveSync { __device__ __forceinline__ void operator()() const { wave_sync(); } };
+
 // Schur form of an m x m (m <= SM = 64) upper Hessenberg matrix held in LDS, by EXPLICITLY shifted QR iterations executed
 // by ONE wave.  Lane c owns column c while Q^H is applied from the left (the rotation that zeroes H[r+1,r] is generated by
 // lane r as soon as its column has received the previous rotations, and broadcast through LDS), and row c while Q is
 // applied from the right (all rotations are known by then, so the lanes run independently).  Compared with a rotation-by-
 // rotation implicit chase this keeps every lane busy and needs no block barrier inside a QR iteration.
 // On return Hs is upper triangular; if Us != nullptr it holds U with H_in = U T U^H.  Returns false if not converged.
-template <class T>
-__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr) {
+// ihi0 / lstop: work on the leading (ihi0 + 1) x (ihi0 + 1) part only and stop as soon as everything below row lstop has deflated
+// (defaults: the whole matrix); *ihi_out receives the index the loop stopped at.
+template <class T, class SY = BlockSync>
+__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr, int ihi0 = -1, int lstop = 0, int* ihi_out = nullptr) {
+    const SY sync;
     const int lane = threadIdx.x;
     long long t_left = 0, t_right = 0, t_u = 0, t_pre = 0, tt = 0, n_it = 0, n_rot = 0;
     if (dbg) tt = clock64();
     const T ulp = eps_of<T>::value;
-    int ihi = m - 1, its = 0, total = 0;
-    while (ihi > 0) {
+    int ihi = ihi0 >= 0 ? ihi0 : m - 1, its = 0, total = 0;
+    while (ihi > lstop) {
         // deflation: flush negligible subdiagonals of [1, ihi] to zero, find the active block [l, ihi]
         int small = 0;
         if (lane >= 1 && lane <= ihi) {
@@ -121,10 +130,10 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         }
         const unsigned long long mask = __ballot(small);
         const int l = mask ? (63 - __builtin_clzll(mask)) : 0;
-        __syncthreads();
+        sync();
         if (l == ihi) { --ihi; its = 0; continue; }
         ++its; ++total;
-        if (total > 40 * m) return false;
+        if (total > 40 * m) { if (ihi_out) *ihi_out = ihi; return false; }
         cx<T> sig;
         {
             const cx<T> a = Hs[(ihi - 1) * SLD + ihi - 1], bq = Hs[(ihi - 1) * SLD + ihi], cq = Hs[ihi * SLD + ihi - 1], d = Hs[ihi * SLD + ihi];
@@ -138,9 +147,9 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
                 sig = (abs1(e1 - d) < abs1(e2 - d)) ? e1 : e2;
             }
         }
-        __syncthreads();
+        sync();
         if (lane >= l && lane <= ihi) Hs[lane * SLD + lane] -= sig;               // H_act - sig I
-        __syncthreads();
+        sync();
         if (dbg) { const long long t1 = clock64(); t_pre += t1 - tt; tt = t1; n_it += 1; n_rot += ihi - l; }
         // left phase: (H_act - sig I) = Q R, rows l..ihi of all columns >= l.  Lane c walks down its column with the
         // running row value carried in registers (one LDS read + one write per rotation, next row prefetched); the
@@ -169,7 +178,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
             }
             if (lane >= ihi && lane < m) Hs[ihi * SLD + lane] = xcur;
         }
-        __syncthreads();
+        sync();
         if (dbg) { const long long t1 = clock64(); t_left += t1 - tt; tt = t1; }
         // right phase: H <- R Q (row i is touched by the rotations r >= i-1), U <- U Q (all rows); each lane walks along
         // its own row with the running column value in registers
@@ -187,7 +196,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
                 Hs[i * SLD + ihi] = x;
             }
         }
-        if (dbg) { __syncthreads(); const long long t1 = clock64(); t_right += t1 - tt; tt = t1; }
+        if (dbg) { sync(); const long long t1 = clock64(); t_right += t1 - tt; tt = t1; }
         if (Us && lane < m && l < ihi) {
             cx<T> x = Us[lane * SLD + l];
             for (int r = l; r < ihi; ++r) {
@@ -198,23 +207,25 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
             }
             Us[lane * SLD + ihi] = x;
         }
-        __syncthreads();
+        sync();
         if (dbg) { const long long t1 = clock64(); t_u += t1 - tt; tt = t1; }
         if (lane >= l && lane <= ihi) Hs[lane * SLD + lane] += sig;
-        __syncthreads();
+        sync();
     }
     if (dbg && lane == 0) { dbg[0] += t_pre; dbg[1] += t_left; dbg[2] += t_right; dbg[3] += t_u; dbg[4] += n_it; dbg[5] += n_rot; }
+    if (ihi_out) *ihi_out = ihi;
     return true;
 }
 
 // Swap the adjacent diagonal entries k, k+1 of the upper-triangular Ts (order m <= 64) by one rotation, accumulating into
 // Vs (LAPACK ztrexc for complex Schur forms).  One wave.
-template <class T>
+template <class T, class SY = BlockSync>
 __device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k, const int SLD) {
+    const SY sync;
     const int lane = threadIdx.x;
     const cx<T> a = Ts[k * SLD + k], bq = Ts[(k + 1) * SLD + k + 1], x = Ts[k * SLD + k + 1];
     const Rot<T> R = rotg_fast(x, bq - a);
-    __syncthreads();
+    sync();
     if (lane >= k && lane < m) {                                   // rows k, k+1: lane = column
         cx<T> u = Ts[k * SLD + lane], v = Ts[(k + 1) * SLD + lane];
         rot_rows(R, u, v);
@@ -225,20 +236,21 @@ __device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k, const int SLD) {
         rot_cols(R, u, v);
         Vs[lane * SLD + k] = u; Vs[lane * SLD + k + 1] = v;
     }
-    __syncthreads();
+    sync();
     if (lane <= k + 1) {                                            // columns k, k+1 of T: lane = row
         cx<T> u = Ts[lane * SLD + k], v = Ts[lane * SLD + k + 1];
         rot_cols(R, u, v);
         if (lane == k + 1) u = cx<T>(T(0), T(0));
         Ts[lane * SLD + k] = u; Ts[lane * SLD + k + 1] = v;
     }
-    __syncthreads();
+    sync();
 }
 
 // Householder reflector for x[0:len] held in LDS at stride `inc` (LAPACK zlarfg): H = I - tau v v^H, H^H x = beta e1.
 // All lanes compute redundantly; v (v[0] = 1) is written to vw[0:len] by the lanes; returns tau, beta.  len <= 64.
-template <class T>
+template <class T, class SY = BlockSync>
 __device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& tau, T& beta) {
+    const SY sync;
     const int lane = threadIdx.x;
     const cx<T> alpha = x[0];
     T xn2 = (lane >= 1 && lane < len) ? norm2(x[lane * inc]) : T(0);
@@ -252,15 +264,16 @@ __device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& 
         tau = cx<T>((beta - alpha.x) / beta, -alpha.y / beta);
         scale = crecip(cx<T>(alpha.x - beta, alpha.y));
     }
-    __syncthreads();
+    sync();
     if (lane < len) vw[lane] = (lane == 0) ? cx<T>(T(1), T(0)) : x[lane * inc] * scale;
-    __syncthreads();
+    sync();
 }
 
 // Apply H = I - tau v v^H (v on rows/cols [o, o+len)) to the m x m Ts from both sides (Ts <- H^H Ts H, left side on
 // columns >= c0, right side on rows < nrows_t) and to Vs from the right (all m rows).  One wave, m <= 64.
-template <class T>
+template <class T, class SY = BlockSync>
 __device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, int o, int len, int c0, const cx<T>* vw, cx<T> tau, const int SLD) {
+    const SY sync;
     const int lane = threadIdx.x;
     if (lane >= c0 && lane < m) {                                   // left: lane = column
         cx<T> w(T(0), T(0));
@@ -268,7 +281,7 @@ __device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, 
         const cx<T> f = conj(tau) * w;
         for (int i = 0; i < len; ++i) Ts[(o + i) * SLD + lane] -= vw[i] * f;
     }
-    __syncthreads();
+    sync();
     if (lane < nrows_t) {                                           // right on T: lane = row
         cx<T> w(T(0), T(0));
         for (int i = 0; i < len; ++i) cfma(w, Ts[lane * SLD + o + i], vw[i]);
@@ -281,7 +294,7 @@ __device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, 
         const cx<T> f = tau * w;
         for (int i = 0; i < len; ++i) Vs[lane * SLD + o + i] -= f * conj(vw[i]);
     }
-    __syncthreads();
+    sync();
 }
 
 template <class T>

@@ -337,8 +337,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(int m, int n, int k, c
 // 73.3 TF-equivalent at 1922^3 x 128, 79.5 vs 80.1 at 4096^3, 29.7 vs 29.9 layer-solves/s in the bench) -- neither the load latency nor the
 // LDS stores nor the second barrier is what holds the 3M product at ~76 % of the matrix-core peak in issued MFMAs.  Default: off.
 static int gemm_dma_env() { const char* e = getenv("TRX_GEMM_DMA"); return (e && atoi(e) == 1) ? 1 : 0; }
-static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); return e ? atoi(e) : 0; }
-static int g_gemm_big = gemm_big_env();       // trx_tuning("gemm_big", 0 .. 3): large-tile fp64 kernel of gemm_big.hip (0 = off; tile configuration)
+// Large-tile fp64 kernel of gemm_big.hip: trx_tuning("gemm_big", v) / TRX_GEMM_BIG, v = 0 automatic (= 3), 1 .. 3 tile configuration
+// (1: 96 x 96 and 2: 128 x 80 with one wave per SIMD and AGPR-pinned accumulators; 3: 128 x 96 with 8 waves), 4 = off (64 x 64 tile
+// of this file).  Measured on MI355X at 1922^3 x 128 (profiles/r04_ab/r4_gemm_big.txt): 73.2 (off) / 79.2 / 80.2 / 83.2 TF-equivalent.
+static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }
+static int g_gemm_big = gemm_big_env();
+static inline int gemm_big_cfg() { return g_gemm_big == 0 ? 3 : (g_gemm_big == 4 ? 0 : g_gemm_big); }
 static int g_gemm_dma = gemm_dma_env();       // trx_tuning("gemm_dma", 0 / 1): fp64 general tile through the direct-to-LDS ring (TRX_GEMM_DMA)
 
 template <class T, int OPA, int OPB>
@@ -383,7 +387,7 @@ int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, 
 
 int gemm_set_knob(const char* key, int value) {
     if (std::string(key) == "gemm_big") {
-        if (value < 0 || value > 3) return TRX_ERR_ARG;
+        if (value < 0 || value > 4) return TRX_ERR_ARG;
         g_gemm_big = value;
         return TRX_OK;
     }
@@ -419,11 +423,12 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
         // block tile: 1922 = 15 x 128 + 2 = 20 x 96 + 2) is peeled off for the flat / narrow tiles of this file instead of costing a
         // whole row / column of almost empty large tiles.
         int bm = 0, bn = 0;
-        if (g_gemm_big) gemm_big_tile(g_gemm_big, &bm, &bn);
-        if (g_gemm_big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64) {
+        const int big = gemm_big_cfg();
+        if (big) gemm_big_tile(big, &bm, &bn);
+        if (big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64) {
             const int rm = (m % bm) <= 32 ? m % bm : 0, rn = (n % bn) <= 32 ? n % bn : 0;
             const int mm = m - rm, nm = n - rn;
-            int rc = gemm_big(s, g_gemm_big, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);
+            int rc = gemm_big(s, big, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);
             if (rc != TRX_OK) return rc;
             if (rm) {      // bottom rows, all columns
                 const cx<T>* Ar = A + (opA == TRX_OP_N ? (long)mm * lda : (long)mm);
