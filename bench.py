@@ -223,8 +223,8 @@ def host_cpu():
 def cpu_baseline(order, grid, lams, eps_sis, threads):
     """The reference's CPU path (oracle/rcwa_oracle.py: same op sequence -- 1 eig / 12 inv / 48 matmul per layer-solve), timed
     on the host cores on a BOUNDED sample: len(lams) sweep points of the same workload in complex64 with denormals NOT flushed
-    (as the reference runs), one of them again with flush-to-zero (footnote), and the first point in complex128
-    (the parity oracle)."""
+    (as the reference runs), one of them again with flush-to-zero (footnote), and every point again in complex128
+    (the parity oracle of the timed sweep)."""
     from oracle import rcwa_oracle as orc
     torch.set_num_threads(threads)
     dens = orc.rectangle_density(grid, grid, 300., 300., 180., 100., 150., 150., dtype=torch.float32)
@@ -244,7 +244,11 @@ def cpu_baseline(order, grid, lams, eps_sis, threads):
     torch.set_flush_denormal(True)
     dt_flush, _ = solve(lams[0], eps_sis[0], torch.complex64)
     torch.set_flush_denormal(False)
-    dt128, v128 = solve(lams[0], eps_sis[0], torch.complex128)
+    dt128, v128 = [], []
+    for lam, e in zip(lams, eps_sis):          # the parity oracle at EVERY baseline point
+        dt, v = solve(lam, e, torch.complex128)
+        dt128.append(dt)
+        v128.append(v)
     return secs, vals, dt_flush, dt128, v128
 
 
@@ -258,6 +262,26 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def csrc_file_hashes():
+    out = {}
+    for p in sorted(glob.glob(os.path.join(ROOT, "torcwa_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "torcwa_amd", "csrc", "*.hpp"))):
+        out[os.path.basename(p)] = hashlib.sha256(open(p, "rb").read()).hexdigest()[:16]
+    return out
+
+
+def profile_valid_for(prof, tag):
+    """A committed profile (kernel trace / counter passes) may be quoted for `tag` when the source files that define the tag's kernels are
+    the ones it was taken on (per-file hashes in the profile; profiles without them: the hash of the whole csrc directory)."""
+    per_file = prof.get("src_sha16")
+    if not per_file:
+        return prof.get("csrc_sha16") == csrc_sha16()
+    files = next((v for k, v in _TAG_SOURCES.items() if tag.startswith(k)), None)
+    now = csrc_file_hashes()
+    if files is None:
+        return per_file == now
+    return all(per_file.get(f) == now.get(f) for f in files)
+
+
 def layer_solve_roof(n, precision):
     """nominal work of one patterned layer-solve, F_dense = 160 n^3, F_eig = 100 n^3 real flops, B_eig,min =
     elem * n^3 / 3 bytes; T_roof = F_dense / P + max(F_eig / P, B_eig,min / 8 TB/s)."""
@@ -268,9 +292,18 @@ def layer_solve_roof(n, precision):
     return out
 
 
-_BOUND = {"gemm_mfma_kernel<N,N>": "mfma", "gemm_mfma_kernel<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm",
+# instrumented tags (torcwa_amd/csrc/prof.hip).  "gemm<N,N>" = one trx gemm() call with both operands untransposed: the large-tile kernel
+# gemm_big_kernel plus the narrow-tile launches that take its thin remainders, or one gemm_mfma_kernel launch for small / panel shapes.
+_BOUND = {"gemm<N,N>": "mfma", "gemm<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm",
           "invit_solve_kernel": "mfma",      # fp64 VECTOR FMAs: on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TF)
-          "gemm_mfma_kernel<N,N> fp32": "mfma", "gemm_mfma_kernel<other ops> fp32": "mfma"}
+          "gemm<N,N> fp32": "mfma", "gemm<other ops> fp32": "mfma"}
+# kernels of a rocprofv3 trace that belong to a tag (prefixes of profiles/kernel_stats.py's short names), and the source files that define them
+# (a committed profile stays valid for a tag as long as THESE files are unchanged; other kernels may have moved on)
+_TRACE_KEYS = {"gemm<N,N>": ("gemm_big_kernel<0, 0", "gemm_mfma_kernel<double, 0, 0"), "gemm<N,N> fp32": ("gemm_mfma_kernel<float, 0, 0",),
+               "apply_window_kernel": ("apply_window_",), "hess_gemv_kernel": ("hess_gemv_kernel",), "qr_prepare_kernel": ("qr_prepare_kernel",),
+               "qr_window_kernel": ("qr_window_kernel",), "hess_col_kernel": ("hess_col_kernel",), "lu_panel_kernel": ("lu_panel_kernel",)}
+_TAG_SOURCES = {"gemm": ("gemm.hip", "gemm_big.hip", "mfma.hpp", "common.hpp", "acc_regs.hpp"), "apply": ("eig_qr.hip", "mfma.hpp", "common.hpp"),
+                "qr_": ("eig_qr.hip", "common.hpp"), "hess": ("eig_hess.hip", "common.hpp"), "lu_": ("lu.hip", "common.hpp")}
 # kernels of the eigensolver proper: with the mixed-precision route (libtrx default for complex128 input, n >= 256, batch >= 8) they run in fp32
 _EIG_STAGE = ("apply_window_kernel", "qr_prepare_kernel", "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel")
 
@@ -312,19 +345,26 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
             # one wave / one workgroup per matrix, dependent chain of small steps: no meaningful flop or byte rate
             k.update(bound="hbm", achieved=0.0, peak=PEAK_HBM_GBS, unit="GB/s", note="latency-bound (one wave or workgroup per matrix)")
         k["frac"] = k["achieved"] / k["peak"]
-        if name in ("apply_window_kernel", "gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>") and not fp32_kernel and k["achieved"] > 0:
+        if name in ("apply_window_kernel", "gemm<N,N>", "gemm<other ops>") and not fp32_kernel and k["achieved"] > 0:
             # fp64 path: 3M complex product, three real MFMAs where the 8-flops-per-complex-MAC count has four
             k["issued_mfma_tflops"] = 0.75 * k["achieved"]
             k["issued_mfma_frac"] = 0.75 * k["frac"]
             k["flop_count_note"] = "achieved counts 8 real flops per complex MAC (TF-equivalent); the 3M product issues 6, so the matrix pipe is at issued_mfma_frac"
-        k.update(profile_fracs(k, args, k["peak"]))
+        k.update(profile_fracs(k, args, k["peak"], steps))
         kernels.append(k)
     kernels.sort(key=lambda k: -k["est_total_ms_per_step"])
     if not kernels:
         return None
     dom = dict(kernels[0])
     dom["chosen_by"] = "largest summed event time (uniform-sample average x launches) among the instrumented kernels"
-    dom["traffic"], dom["traffic_note"] = pmc_traffic(dom["kernel"], args)
+    dom["traffic"], dom["traffic_note"] = pmc_traffic(dom, args, steps)
+    if dom["traffic"] and dom.get("algorithmic_flops_per_launch"):
+        # which roof binds, from the MEASURED traffic: time the bytes need at the HBM peak against the time the issued flops need at the matrix peak
+        issued = dom["algorithmic_flops_per_launch"] * (0.75 if "issued_mfma_frac" in dom else 1.0)
+        t_hbm, t_mfma = dom["traffic"] / (PEAK_HBM_GBS * 1e9), issued / (dom["peak"] * 1e12)
+        dom["bound"] = "hbm" if t_hbm > t_mfma else "mfma"
+        dom["bound_note"] = "measured traffic %.1f GB per call = %.2f ms at 8 TB/s vs %.2f ms of issued matrix-core work at the peak; %.1fx the algorithmic bytes" % (
+            dom["traffic"] / 1e9, 1e3 * t_hbm, 1e3 * t_mfma, dom["traffic"] / max(dom.get("algorithmic_bytes_per_launch", 0.0), 1.0))
     t_meas = 1e3 * elapsed / (steps * units_per_step)
     roofs = layer_solve_roof(n, args.precision)
     dom["layer_solve"] = {
@@ -338,75 +378,70 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
     return dom
 
 
-PROFILE_TAG = "r03"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
+PROFILE_TAG = "r04"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
 
 
-def profile_fracs(k, args, peak):
-    """The same kernel's roofline fraction recomputed from the COMMITTED profiles, so that the line and profiles/ can be held against each
-    other: `frac_rocprof` = algorithmic work per launch / the rocprofv3 --kernel-trace average duration (in situ, kernels of the other
-    iteration groups running next to it), `frac_alone` = the same with the duration from the --pmc passes (rocprofv3 serialises kernels
-    there).  Both are refused unless the profile was taken on the same kernel sources (hash of torcwa_amd/csrc) at this batch size."""
+def _tag_kernels(prof, name):
+    keys = _TRACE_KEYS.get(name)
+    if not keys:
+        return []
+    return [v for k_, v in prof.get("kernels", {}).items() if k_.startswith(keys)]
+
+
+def profile_fracs(k, args, peak, steps):
+    """The same tag's roofline fraction recomputed from the COMMITTED profiles, so that the line and profiles/ can be held against each
+    other: `frac_rocprof` = algorithmic work of the tag per step / the summed duration of its kernels per step in the rocprofv3
+    --kernel-trace of the same command (in situ, kernels of the other iteration groups running next to it), `frac_alone` = the same with the
+    durations of the --pmc passes (rocprofv3 serialises kernels there).  A gemm() call is one to three launches (large tile + peeled
+    remainders), hence per-step sums on both sides.  Refused unless the profile was taken on the same sources OF THESE KERNELS at this batch."""
     out = {}
     work = k.get("algorithmic_flops_per_launch") if k.get("bound") == "mfma" else k.get("algorithmic_bytes_per_launch")
-    if not work or args.config != 2:
-        return out
     name = k["kernel"]
-    if "other ops" in name:          # several instantiations under one tag: no single kernel of the trace to hold it against
+    if not work or args.config != 2 or name not in _TRACE_KEYS:
         return out
-    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float"),
-           "gemm_mfma_kernel<N,N> fp32": "gemm_mfma_kernel<float, 0, 0", "apply_window_kernel": "apply_window_"}.get(name, name.split("<")[0])
-    for field, fn, dur in (("frac_rocprof", "%s_kernel_profile.json" % PROFILE_TAG, lambda v: v["avg_us"]),
-                           ("frac_alone", "%s_pmc_bench.json" % PROFILE_TAG, lambda v: 1e3 * v["ms_total"] / max(v["launches"], 1))):
+    work_per_step = work * k["launches"] / steps
+    for field, fn in (("frac_rocprof", "%s_kernel_profile.json" % PROFILE_TAG), ("frac_alone", "%s_pmc_bench.json" % PROFILE_TAG)):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except (OSError, ValueError):
             out[field], out[field + "_note"] = None, "profiles/%s not committed" % fn
             continue
-        if prof.get("csrc_sha16") != csrc_sha16() or prof.get("batch") != args.batch:
-            out[field], out[field + "_note"] = None, "profiles/%s was taken on other kernel sources or another batch size: refused" % fn
+        if not profile_valid_for(prof, name) or prof.get("batch") != args.batch:
+            out[field], out[field + "_note"] = None, "profiles/%s was taken on other sources of this kernel or another batch size: refused" % fn
             continue
-        kk = [v for k_, v in prof.get("kernels", {}).items() if k_.startswith(key)]
+        kk = _tag_kernels(prof, name)
         if not kk:
             out[field], out[field + "_note"] = None, "kernel not in profiles/%s" % fn
             continue
-        n_l = sum(v["launches"] for v in kk)
-        avg_us = sum(dur(v) * v["launches"] for v in kk) / n_l
-        rate = work / (avg_us * 1e-6) / (1e12 if k.get("bound") == "mfma" else 1e9)
+        ms_per_step = sum(v.get("total_ms", v.get("ms_total", 0.0)) for v in kk) / max(prof.get("steps_traced", 1), 1)
+        rate = work_per_step / (ms_per_step * 1e-3) / (1e12 if k.get("bound") == "mfma" else 1e9)
         out[field] = rate / peak
-        out[field + "_note"] = "%.1f us average over %d launches in profiles/%s" % (avg_us, n_l, fn)
+        out[field + "_note"] = "%.1f ms per step over %d launches per step in profiles/%s" % (
+            ms_per_step, sum(v["launches"] for v in kk) // max(prof.get("steps_traced", 1), 1), fn)
     return out
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot
-    be collected from inside this process).  Accepted only when the summary was taken on the SAME kernel sources (hash of
-    torcwa_amd/csrc) and at this batch size -- otherwise null."""
-    path = os.path.join(ROOT, "profiles", "%s_pmc_bench.json" % PROFILE_TAG)
+def pmc_traffic(dom, args, steps):
+    """HBM-side bytes per call of the dominant tag from the separate rocprofv3 --pmc passes (profiles/scripts/pmc_bench.sh; counters cannot
+    be collected from inside this process): 2 x FETCH_SIZE + WRITE_SIZE summed over the tag's kernels, per step, divided by the calls per
+    step.  Accepted only when the summary was taken on the same sources of these kernels and at this batch size -- otherwise null."""
+    fn = "%s_pmc_bench.json" % PROFILE_TAG
     try:
-        pmc = json.load(open(path))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
     except (OSError, ValueError):
-        note = "no PMC summary committed for this round (the counter passes of the round's evidence call were cut off, profiles/README.md)"
-        try:          # the previous round's figure for the same kernel name, as a pointer only: other kernel sources, so `traffic` stays null
-            prev = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench.json")))
-            key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<double, 0, 0"}.get(kernel, kernel.split("<")[0])
-            kk = [v for k_, v in prev.get("kernels", {}).items() if k_.startswith(key)]
-            if kk and prev.get("batch") == args.batch and args.config == 2 and args.precision == "high":
-                note += "; round 2 measured %.1f MB per launch for this kernel (profiles/r02_pmc_bench.json, batch %d)" % (
-                    sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk) / sum(v["launches"] for v in kk) / 1e6, prev["batch"])
-        except (OSError, ValueError, KeyError):
-            pass
-        return None, note
-    if pmc.get("csrc_sha16") != csrc_sha16():
-        return None, "profiles/r03_pmc_bench.json was taken on other kernel sources (csrc hash %s != %s): refused" % (pmc.get("csrc_sha16"), csrc_sha16())
+        return None, "profiles/%s not committed" % fn
+    if not profile_valid_for(pmc, dom["kernel"]):
+        return None, "profiles/%s was taken on other sources of this kernel: refused" % fn
     if pmc.get("batch") != args.batch or args.config != 2:
-        return None, "profiles/r03_pmc_bench.json was taken at another workload"
-    key = {"gemm_mfma_kernel<N,N>": "gemm_mfma_kernel<%s, 0, 0" % ("double" if args.precision == "high" else "float")}.get(kernel, kernel.split("<")[0])
-    kk = [v for k_, v in pmc.get("kernels", {}).items() if k_.startswith(key)]
+        return None, "profiles/%s was taken at another workload" % fn
+    kk = _tag_kernels(pmc, dom["kernel"])
     if not kk:
         return None, "kernel not in the PMC summary"
-    tot = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk)
-    return tot / sum(v["launches"] for v in kk), ("HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of the same command, "
-                                                  "same kernel sources): profiles/r03_pmc_bench.json")
+    per_step = sum(v["bytes_per_launch_corrected"] * v["launches"] for v in kk) / max(pmc.get("steps_traced", 1), 1)
+    calls_per_step = dom["launches"] / steps
+    return per_step / calls_per_step, ("bytes per call crossing the L2 -> fabric boundary (2*FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, "
+                                       "so this bounds the HBM traffic from above), separate --pmc passes of the same command restricted to these kernels, "
+                                       "same kernel sources: profiles/%s" % fn)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -593,11 +628,14 @@ def main():
             npts = max(1, min(args.cpu_points, len(lam)))
             pick = sorted(set(int(round(i * (len(lam) - 1) / max(npts - 1, 1))) for i in range(npts)))
             secs, vals, dt_flush, dt128, v128 = cpu_baseline(order, args.grid, [lam[i] for i in pick], [eps_si[i] for i in pick], threads)
-            got = complex(full[pick[0], 0])
-            res["parity_sample"] = {"point": "lambda=%.1f nm, txx(0,0)" % lam[pick[0]], "gpu": [got.real, got.imag],
-                                    "oracle_c128": [v128.real, v128.imag], "rel_err_vs_c128_oracle": abs(got - v128) / abs(v128),
-                                    "oracle_c64": [vals[0].real, vals[0].imag], "rel_err_of_c64_oracle_vs_c128_oracle": abs(vals[0] - v128) / abs(v128),
-                                    "oracle_c128_seconds": dt128}
+            pts = []
+            for j, i in enumerate(pick):
+                got = complex(full[i, 0])
+                pts.append({"point": "lambda=%.1f nm, txx(0,0)" % lam[i], "gpu": [got.real, got.imag], "oracle_c128": [v128[j].real, v128[j].imag],
+                            "rel_err_vs_c128_oracle": abs(got - v128[j]) / abs(v128[j]), "oracle_c64": [vals[j].real, vals[j].imag],
+                            "rel_err_of_c64_oracle_vs_c128_oracle": abs(vals[j] - v128[j]) / abs(v128[j]), "oracle_c128_seconds": dt128[j]})
+            res["parity_sample"] = dict(pts[0], all_points=pts, max_rel_err_vs_c128_oracle=max(p_["rel_err_vs_c128_oracle"] for p_ in pts),
+                                        gate="<= 1e-5 (north_star): complex64-I/O result of the timed sweep against the complex128 oracle at every CPU-baseline point")
             res["cpu_baseline"] = {"value": len(secs) / sum(secs), "unit": "layer-solves/s", "cores": threads, "kind": "port",
                                    "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
                                    "seconds_per_layer_solve": secs, "flush_denormal_seconds_footnote": dt_flush,

@@ -238,13 +238,16 @@ def to_json(path, out, batch, command):
     import json
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import csrc_sha16
+    import re
+    from bench import csrc_sha16, csrc_file_hashes
+    m_steps, m_warm = re.search(r"--steps (\d+)", command), re.search(r"--warmup (\d+)", command)
+    steps_traced = (int(m_steps.group(1)) if m_steps else 1) + (int(m_warm.group(1)) if m_warm else 0)
     agg = {}
     for name, start, end in sqlite3.connect(path).cursor().execute("select name, start, end from kernels"):
         a = agg.setdefault(short(name), [0, 0])
         a[0] += 1
         a[1] += end - start
-    js = {"csrc_sha16": csrc_sha16(), "batch": int(batch), "command": command,
+    js = {"csrc_sha16": csrc_sha16(), "src_sha16": csrc_file_hashes(), "batch": int(batch), "command": command, "steps_traced": steps_traced,
           "kernels": {k: {"launches": a[0], "avg_us": a[1] / a[0] / 1e3, "total_ms": a[1] / 1e6} for k, a in agg.items()}}
     json.dump(js, open(out, "w"), indent=1)
 

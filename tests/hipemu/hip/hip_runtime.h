@@ -289,6 +289,7 @@ inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 template <class T>
 inline T __builtin_amdgcn_readfirstlane(T v) { return __shfl(v, 0); }
+inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
 
 // ---- MFMA (fragment maps per /opt/skills/guides/cdna_hip_programming.md section 3) --------------------
 typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));

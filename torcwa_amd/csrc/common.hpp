@@ -144,6 +144,19 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// Value of lane `l` (WAVE-UNIFORM) in every lane: v_readlane_b32 per dword, a register-to-scalar move (no LDS round trip like __shfl's
+// ds_bpermute).
+template <class T> __device__ __forceinline__ T bcast_lane(T v, int l) {
+    static_assert(sizeof(T) % 4 == 0, "dword multiple");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = __builtin_amdgcn_readlane(w[i], l);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+
 // Ordering point inside a wave: lanes of one wavefront execute in lock-step, so this emits no instruction on gfx950; it
 // stops the compiler from moving LDS accesses across it (and is a rendezvous in the CPU kernel-logic emulator).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }

@@ -110,7 +110,9 @@ struct WaveSync { __device__ __forceinline__ void operator()() const { wave_sync
 // On return Hs is upper triangular; if Us != nullptr it holds U with H_in = U T U^H.  Returns false if not converged.
 // ihi0 / lstop: work on the leading (ihi0 + 1) x (ihi0 + 1) part only and stop as soon as everything below row lstop has deflated
 // (defaults: the whole matrix); *ihi_out receives the index the loop stopped at.
-template <class T, class SY = BlockSync>
+// BC: the inputs (f, g) of rotation r are broadcast from lane r with v_readlane and EVERY lane generates the rotation, instead of lane r
+// generating it and five ds_bpermute shuffles distributing the result (one LDS round trip less on the chain of every rotation).
+template <class T, class SY = BlockSync, bool BC = false>
 __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr, int ihi0 = -1, int lstop = 0, int* ihi_out = nullptr) {
     const SY sync;
     const int lane = threadIdx.x;
@@ -161,11 +163,15 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
             for (int r = l; r < ihi; ++r) {
                 const cx<T> ypre = (mine && r + 2 <= ihi) ? Hs[(r + 2) * SLD + lane] : cx<T>(T(0), T(0));   // prefetch
                 Rot<T> R;
-                R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0));
-                if (lane == r) R = rotg_fast(xcur, ynext);
-                R.c = __shfl(R.c, r);
-                R.s.x = __shfl(R.s.x, r); R.s.y = __shfl(R.s.y, r);
-                R.r.x = __shfl(R.r.x, r); R.r.y = __shfl(R.r.y, r);
+                if constexpr (BC) {
+                    R = rotg_fast(bcast_lane(xcur, r), bcast_lane(ynext, r));
+                } else {
+                    R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0));
+                    if (lane == r) R = rotg_fast(xcur, ynext);
+                    R.c = __shfl(R.c, r);
+                    R.s.x = __shfl(R.s.x, r); R.s.y = __shfl(R.s.y, r);
+                    R.r.x = __shfl(R.r.x, r); R.r.y = __shfl(R.r.y, r);
+                }
                 if (lane == r) rots[r] = R;
                 if (lane >= r && lane < m) {
                     cx<T> x = xcur, y = ynext;
@@ -182,6 +188,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         if (dbg) { const long long t1 = clock64(); t_left += t1 - tt; tt = t1; }
         // right phase: H <- R Q (row i is touched by the rotations r >= i-1), U <- U Q (all rows); each lane walks along
         // its own row with the running column value in registers
+        {
         if (lane <= ihi) {
             const int i = lane;
             const int r0 = (i - 1 > l) ? i - 1 : l;
@@ -209,6 +216,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         }
         sync();
         if (dbg) { const long long t1 = clock64(); t_u += t1 - tt; tt = t1; }
+        }
         if (lane >= l && lane <= ihi) Hs[lane * SLD + lane] += sig;
         sync();
     }
@@ -335,7 +343,7 @@ __device__ __forceinline__ int plan_chains(QrState& st, int ilo, int ihi, int av
 // position (0 = top of the shift list, ktot-1 = bottom-most eigenvalue) of shift s of chain c: chain 0 takes the bottom QNS
 __device__ __forceinline__ int chain_shift_pos(const QrState& st, int ktot, int c, int s) { return ktot - QNS * c - st.k[c] + s; }
 
-template <class T>
+template <class T, bool BC>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
         }
         __syncthreads();
-        const bool ok = small_schur<T>(Hs, m, Us, rots, SLD);
+        const bool ok = small_schur<T, BlockSync, BC>(Hs, m, Us, rots, SLD);
         __syncthreads();
         cx<T>* U = Uall + (long)b * QKC * QW * QW;            // chain slot 0 carries the unitary of a finished block / AED window
         for (int e = lane; e < m * m; e += 64) {
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[6] += t1 - tk0; tk0 = t1; }       // scans + window load
-    const bool okw = small_schur<T>(Hs, nw, Us, rots, SLD, dbg);
+    const bool okw = small_schur<T, BlockSync, BC>(Hs, nw, Us, rots, SLD, dbg);
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[7] += t1 - tk0; tk0 = t1; }       // Schur total
     int ns = nw;
@@ -1337,7 +1345,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, rotb = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1360,6 +1368,7 @@ static QrKnobs& qr_knobs() {
         q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
         q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
+        q.rotb = geti("TRX_QR_ROTB", 0, 2, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1409,6 +1418,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_aed") { slot = &k.aed; hi = QAED; }
     else if (s == "qr_nibble") { slot = &k.nibble; hi = 100; }
     else if (s == "qr_moves") { slot = &k.moves; hi = QAED; }
+    else if (s == "qr_rotb") { slot = &k.rotb; hi = 2; }
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
     else if (s == "slab_dyn") { slot = &k.dyn; hi = 2; }
     else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
@@ -1442,7 +1452,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
                   set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
-                  set_max_dyn_smem((const void*)qr_prepare_kernel<T>, smp_of(SM));
+                  set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
             stt = r ? 2 : 1;
         }
         attr_rc = stt == 2;
@@ -1537,9 +1547,14 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int* sum = G.summary + 4 * slot;
         if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
-          TRX_LAUNCH((qr_prepare_kernel<T>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                     B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
-                     (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
+          if (K.rotb == 1)
+              TRX_LAUNCH((qr_prepare_kernel<T, false>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
+                         (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
+          else
+              TRX_LAUNCH((qr_prepare_kernel<T, true>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
+                         (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
     };

@@ -110,8 +110,8 @@ extern "C" int trx_prof_get(int tag, double* out) {
 }
 
 extern "C" const char* trx_prof_tag_name(int tag) {
-    static const char* names[PROF_NTAGS] = {"gemm_mfma_kernel<N,N>", "gemm_mfma_kernel<other ops>", "qr_prepare_kernel", "apply_window_kernel",
+    static const char* names[PROF_NTAGS] = {"gemm<N,N>", "gemm<other ops>", "qr_prepare_kernel", "apply_window_kernel",
                                             "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel", "invit_solve_kernel",
-                                            "gemm_mfma_kernel<N,N> fp32", "gemm_mfma_kernel<other ops> fp32"};
+                                            "gemm<N,N> fp32", "gemm<other ops> fp32"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }
