@@ -106,7 +106,7 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *   "invit_cfg"   0-6   layout of the inverse-iteration kernel (TRX_INVIT_CFG): 0/1 512 threads, register prefetch 2 deep; 2: 3 deep;
  *                       3: 1 deep; 4: 1024 threads; 5 / 6: 1024 / 512 threads with the direct-to-LDS column ring
  *   "invit_ring"  1-3 (register variants) or 3-4 (ring variants) columns of H resident in LDS;  "invit_wpl" 1, 2, 4, 8: minimum waves
- *                       per eigenvalue (tests);  "invit_xcd" 1 = plain 2-D grid instead of the XCD-aware launches;  "invit_dbg": timing experiments
+ *                       per eigenvalue (tests);  "invit_xcd" 1 = plain 2-D grid instead of the XCD-aware launches
  *   GEMM (trx_gemm and every product inside the library)
  *   "gemm_big"    large-tile complex128 kernel for outputs of at least 2 x 2 of its tiles and k >= 64 (TRX_GEMM_BIG): 1 = 96 x 96 and 2 = 128 x 80
  *                       with one wave per SIMD, 3 = 128 x 96 with 8 waves, 4 = off (64 x 64 tile)                    auto: 3

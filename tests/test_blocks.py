@@ -352,3 +352,35 @@ def test_lu_row_split_nan_matrix_stays_in_bounds(backend, where):
     X = np.linalg.solve(A[good], B[good])
     Xg = hB[:batch * n * nrhs].reshape(batch, n, nrhs)[good]
     assert np.abs(Xg - X).max() / np.abs(X).max() < 1e-10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("n,batch,split", [(530, 2, 0), (777, 1, 128), (1100, 1, 0)])
+def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
+    """Look-ahead LU (knob lu_look; automatic from n = 1024): the next outer block's panels are factored on a side stream under the trailing
+    update of the remaining columns, and a block's row interchanges reach the columns outside the block only when the block is done.  The
+    panels see the same data in the same order, so pivots AND factors must equal the sequential schedule bit for bit (n = 530 / 777: two /
+    three outer blocks + a short tail with the schedule forced on; n = 1100: the automatic regime)."""
+    be = get_backend(backend)
+    if backend == "emu" and n > 800:
+        pytest.skip("emulator: the two smaller sizes cover the schedule")
+    A = crand((batch, n, n), dtype)
+    A[0, :, 3] *= 1e-3
+    B = crand((batch, n, 5), dtype)
+    res = []
+    for look in (1, 2 if n < 1024 else 0):          # 1: off; 2: forced on; 0: automatic
+        assert be.lib.tuning(b"lu_look", look) == 0 and be.lib.tuning(b"lu_split", split) == 0
+        try:
+            dA, dB = be.dev(A), be.dev(B)
+            piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+            assert be.lib.lu_solve(dtcode(dtype), be.ptr(dA), n, be.ptr(dB), 5, batch, be.ptr(piv), be.ptr(info), be.stream) == 0
+        finally:
+            be.lib.tuning(b"lu_look", 0)
+            be.lib.tuning(b"lu_split", 0)
+        assert (be.host(info) == 0).all()
+        res.append((be.host(dA), be.host(dB), be.host(piv)))
+    assert (res[0][2] == res[1][2]).all()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    X = np.linalg.solve(A.astype(np.complex128), B.astype(np.complex128))
+    assert np.abs(res[1][1] - X).max() / np.abs(X).max() < (1e-10 if dtype == np.complex128 else 5e-3)

@@ -96,3 +96,34 @@ def test_blockdiag2_algebra():
     assert torch.allclose((A @ B).dense(), A.dense() @ B.dense())
     assert torch.allclose(A.inv().dense(), torch.linalg.inv(A.dense()))
     assert torch.allclose((A + B).dense(), A.dense() + B.dense())
+
+
+def test_bench_profile_bookkeeping(tmp_path, monkeypatch):
+    """bench.py holds its live roofline figures against the committed profiles per TAG: a gemm<N,N> call is the large-tile kernel plus the
+    narrow-tile launches of its peeled remainders, so work and kernel time are compared per step; a profile is accepted for a tag while the
+    source files of THAT tag's kernels are unchanged, and refused otherwise."""
+    import json
+    import types
+    import bench
+    hashes = bench.csrc_file_hashes()
+    assert "gemm_big.hip" in hashes and "common.hpp" in hashes
+    prof = {"csrc_sha16": "x", "src_sha16": dict(hashes), "batch": 128, "steps_traced": 4,
+            "kernels": {"gemm_big_kernel<0, 0, 4, 2, 2, 3, false>": {"launches": 40, "avg_us": 1000.0, "total_ms": 40.0},
+                        "gemm_mfma_kernel<double, 0, 0, 2, 4, 16>": {"launches": 40, "avg_us": 50.0, "total_ms": 2.0},
+                        "gemm_mfma_kernel<float, 0, 0, 4, 4, 16>": {"launches": 8, "avg_us": 10.0, "total_ms": 0.08},
+                        "hess_gemv_kernel<float, 2>": {"launches": 400, "avg_us": 100.0, "total_ms": 40.0}}}
+    assert bench.profile_valid_for(prof, "gemm<N,N>") and bench.profile_valid_for(prof, "hess_gemv_kernel")
+    moved = dict(prof, src_sha16=dict(hashes, **{"eig_hess.hip": "0" * 16}))
+    assert bench.profile_valid_for(moved, "gemm<N,N>") and not bench.profile_valid_for(moved, "hess_gemv_kernel")
+    moved = dict(prof, src_sha16=dict(hashes, **{"gemm_big.hip": "0" * 16}))
+    assert not bench.profile_valid_for(moved, "gemm<N,N>") and bench.profile_valid_for(moved, "hess_gemv_kernel")
+    assert not bench.profile_valid_for({"csrc_sha16": "other"}, "gemm<N,N>")            # legacy profile without per-file hashes
+    # per-step accounting: 10 calls per step of 1e12 flops each against (40 + 2) ms / 4 steps of kernel time
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / ("%s_kernel_profile.json" % bench.PROFILE_TAG)).write_text(json.dumps(prof))
+    monkeypatch.setattr(bench, "csrc_file_hashes", lambda: hashes)
+    args = types.SimpleNamespace(config=2, batch=128, precision="high")
+    k = {"kernel": "gemm<N,N>", "bound": "mfma", "algorithmic_flops_per_launch": 1e12, "launches": 20}
+    out = bench.profile_fracs(k, args, 78.6, steps=2)
+    assert abs(out["frac_rocprof"] - (10 * 1e12 / 10.5e-3 / 1e12) / 78.6) < 1e-9 and out["frac_alone"] is None

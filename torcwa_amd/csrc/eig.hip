@@ -175,7 +175,7 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             cx<float>* w32 = (cx<float>*)p;
             rc = eig_mixed_convert(s, (const cx<double>*)A, A32, (long)Bn * N * N);
             if (rc) return rc;
-            rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32);      // (its info is folded into the flags below)
+            rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32);      // its info reaches eig_refine in R.linfo and is folded into the flags there
             if (rc) return rc;
             RefineBuffers<T> R;
             R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;

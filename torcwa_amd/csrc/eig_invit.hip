@@ -37,7 +37,11 @@ static int g_invit_cfg = invit_cfg_env(), g_invit_min_wpl = 0, g_invit_ring = 0,
 int invit_set_knob(const char* key, int value) {
     const std::string k(key);
     if (k == "invit_cfg" && value >= 0 && value <= 6) { g_invit_cfg = value; return TRX_OK; }
-    if (k == "invit_dbg" && value >= 0 && value <= 15) { g_invit_dbg = value; return TRX_OK; }      // timing experiments only (skips parts of the step)
+#ifdef TRX_INVIT_DEBUG
+    // timing experiments of round 3 only: the bits SKIP barriers and parts of the solve step, i.e. they change results -- not a tuning knob of
+    // the library (include/trx.h: "results do not depend on any knob"), compiled in only with -DTRX_INVIT_DEBUG
+    if (k == "invit_dbg" && value >= 0 && value <= 15) { g_invit_dbg = value; return TRX_OK; }
+#endif
     if (k == "invit_xcd" && value >= 0 && value <= 1) { g_invit_xcd = value; return TRX_OK; }
     if (k == "invit_ring" && value >= 0 && value <= 3) { g_invit_ring = value; return TRX_OK; }
     if (k == "invit_wpl" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_invit_min_wpl = value; return TRX_OK; }

@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restric
         if (i == j) { lam[(long)b * n + i] = G[e]; d0[(long)b * n + i] = G[e]; lm = a > lm ? a : lm; }
         else eo = (a > eo || !(a == a)) ? a : eo;                      // a NaN sticks
     }
-    eo = wave_max(eo); lm = wave_max(lm);
+    // NaN-propagating maximum: wave_max keeps whichever operand wins `w > v`, so a NaN held by only some lanes could drop out
+    const bool has_nan = __any(!(eo == eo));
+    eo = wave_max(has_nan ? T(0) : eo);
+    if (has_nan) eo = (T)__builtin_nan("");
+    lm = wave_max(lm);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = eo; red[1][threadIdx.x >> 6] = lm; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -359,6 +363,13 @@ __global__ __launch_bounds__(256) void refine_build_inplace_kernel(cx<T>* __rest
     *g = (k == j) ? cx<T>(T(1), T(0)) : cdiv(*g, d0[j] - d0[k]);
 }
 
+// flags[b] |= 1 where the fp32 eigensolver reported unconverged eigenvalues (its info array is the LU's info array and is cleared by the
+// first lu_factor below, so it is folded into the flags before that)
+__global__ void refine_fold_info_kernel(int* __restrict__ flags, const int* __restrict__ info32, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && info32[b] != 0) atomicOr(&flags[b], 1);
+}
+
 template <class T>
 __global__ void refine_or_info_kernel(const int* __restrict__ flags, const int* __restrict__ linfo, int* __restrict__ any, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,6 +399,7 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
     TRX_LAUNCH((cvt_kernel<float, T>), dim3(cdiv_i(cntV, 256)), dim3(256), 0, s, V32, buf[cur], cntV);
     TRX_LAUNCH((cvt_kernel<float, T>), dim3(cdiv_i(cntw, 256)), dim3(256), 0, s, w32, w, cntw);
     if (hipMemsetAsync(R.flags, 0, sizeof(int) * (batch + 1), s) != hipSuccess) return TRX_ERR_LAUNCH;
+    TRX_LAUNCH(refine_fold_info_kernel, dim3(cdiv_i(batch, 64)), dim3(64), 0, s, R.flags, (const int*)R.linfo, batch);     // R.linfo: info of the fp32 solve on entry
     for (int it = 0; it < steps; ++it) {
         cx<T>* Vc = buf[cur];
         cx<T>* Vn = buf[cur ^ 1];

@@ -5,13 +5,15 @@
 //
 // Blocked right-looking algorithm, panel width NB:
 //   lu_panel_kernel      one workgroup per matrix factors the (n-k0) x jb panel (pivot search = block reduction)
-//   lu_swap_kernel       applies the panel's row interchanges to the columns left and right of the panel
+//   lu_swap_range_kernel applies row interchanges to two column windows (inside the outer block per panel, outside it per block)
 //   trsm_lower_kernel    U12 = L11^-1 A12      (one thread per column, L11 broadcast from LDS)
 //   gemm                 A22 -= L21 U12
 #include "common.hpp"
 #include <cstdlib>
 #include "prof.hpp"
+#include <mutex>
 #include <string>
+#include <vector>
 
 namespace trx {
 namespace {
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(512) void lu_panel_kernel(cx<T>* __restrict__ Aall,
 //                           for column j+1 -> cand[(j+1)&1][w].  The rows chosen so far are the <= jb entries piv[k0..k0+j).
 //   lu_split_scale_kernel   scales the multipliers (kept unscaled while the columns are eliminated, like in the one-workgroup kernel)
 //   lu_split_final_kernel   turns the list of chosen rows into LAPACK's sequential interchanges (piv[k0+j] = position swapped with
-//                           position k0+j) and applies them to the panel columns; lu_swap_kernel then does the other columns as
+//                           position k0+j) and applies them to the panel columns; lu_swap_range_kernel then does the other columns as
 //                           usual.  Row k0+j ends up as [multipliers of columns < j | U row j]: the standard layout.
 // The pivot of each column is the same largest-magnitude element as in the one-workgroup kernel (exact ties may resolve to another
 // row: the candidates are ordered by their original row index, not by their current position).
@@ -310,22 +312,22 @@ __global__ __launch_bounds__(64) void lu_split_final_kernel(cx<T>* __restrict__ 
     }
 }
 
-// Apply interchanges piv[k0 .. k0+jb) to every column outside [k0, k0+jb).
+// Apply the interchanges piv[k0 .. k0+np) to the columns [a0, a1) and [b0, b1) (the two column windows either side of an outer block).
 template <class T>
-__global__ __launch_bounds__(256) void lu_swap_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int ncols_total, int k0, int jb,
-                                                       const int* __restrict__ piv_all, int n) {
+__global__ __launch_bounds__(256) void lu_swap_range_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int a0, int a1, int b0, int b1, int k0, int np,
+                                                             const int* __restrict__ piv_all, int n) {
     const int b = blockIdx.y;
     cx<T>* A = Aall + (long)b * sA;
     const int* piv = piv_all + (long)b * n;
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols_total - jb) return;
-    if (c >= k0) c += jb;
-    for (int j = 0; j < jb; ++j) {
+    if (c >= (a1 - a0) + (b1 - b0)) return;
+    c = c < a1 - a0 ? a0 + c : b0 + (c - (a1 - a0));
+    for (int j = 0; j < np; ++j) {
         const int r = k0 + j, p = piv[r];
         if (p != r) {
-            cx<T> a = A[(long)r * lda + c];
+            cx<T> t = A[(long)r * lda + c];
             A[(long)r * lda + c] = A[(long)p * lda + c];
-            A[(long)p * lda + c] = a;
+            A[(long)p * lda + c] = t;
         }
     }
 }
@@ -405,6 +407,8 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
+static int lu_look_env() { const char* e = getenv("TRX_LU_LOOK"); return e ? atoi(e) : 0; }
+static int g_lu_look = lu_look_env();         // trx_tuning("lu_look", v): 0 automatic (look-ahead for n >= 1024), 1 off, 2 always (tests)
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
@@ -413,7 +417,111 @@ int lu_set_knob(const char* key, int value) {
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
     if (k == "lu_split") g_lu_split_rows = value;
     else if (k == "lu_split_batch") g_lu_split_batch = value;
+    else if (k == "lu_look") { if (value > 2) return TRX_ERR_ARG; g_lu_look = value; }
     else return TRX_ERR_ARG;
+    return TRX_OK;
+}
+
+// ---- look-ahead --------------------------------------------------------------------------------------------------------------
+// The panels of an outer block are chains of short launches (one per panel column: 50 us each, latency-bound, 0.3 s of a 4 s bench step
+// over its nine factorisations), the rank-256 trailing update behind them is one matrix-core-bound launch; run one after the other
+// neither fills the chip.  With look-ahead the trailing update of outer block K is split at the next block's columns: those 256 columns
+// are updated first, then a side stream factors block K+1 there while the main stream updates the rest.  What makes the two independent is
+// that a block's row interchanges are applied to the columns OUTSIDE the block only when the block is finished (lu_swap_range_kernel, on
+// the main stream after the join) -- inside the block the panels see exactly the data and choose exactly the pivots they did before, so
+// the factors are bit-identical to the sequential order.  Stream and events come from a process-wide pool (nothing is created per call
+// after the first, no host synchronisation).
+struct LuLane { hipStream_t s2 = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr; int dev = -1; };
+static std::mutex g_lu_lane_mu;
+static std::vector<LuLane> g_lu_lane_free;
+static bool lu_lane_checkout(LuLane& out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_lu_lane_mu);
+        for (size_t i = 0; i < g_lu_lane_free.size(); ++i)
+            if (g_lu_lane_free[i].dev == dev) { out = g_lu_lane_free[i]; g_lu_lane_free.erase(g_lu_lane_free.begin() + i); return true; }
+    }
+    out = LuLane();
+    out.dev = dev;
+    return hipStreamCreateWithFlags(&out.s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&out.e1, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&out.e2, hipEventDisableTiming) == hipSuccess;
+}
+static void lu_lane_return(const LuLane& l) {
+    std::lock_guard<std::mutex> lock(g_lu_lane_mu);
+    g_lu_lane_free.push_back(l);
+}
+
+// Panels of the outer block [K0, Kend) on stream s; row interchanges applied inside the block's columns only.
+template <class T>
+int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, int Kend, int* piv, int batch, int* info) {
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
+    auto at = [&](int r, int c) { return A + (long)r * lda + c; };
+    for (int c0 = K0; c0 < Kend; c0 += NB) {
+        const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+        // few large matrices: row-split panel (see above); needs 2 W ints of the pivot array's unwritten tail
+        const int rows = n - c0;
+        const int split_min = g_lu_split_rows ? g_lu_split_rows : 1024;
+        // workgroups per matrix: about 512 per launch over the batch, at least 64 rows each (a larger batch already supplies
+        // workgroups, but the one-workgroup panel still leaves half of the CUs idle at batch 128: knob lu_split_batch)
+        // measured on MI355X (round 3): the row-split panel also wins at batch 16 and 128 (+1.3 % of the whole layer-solve step each)
+        const int split_batch = g_lu_split_batch ? g_lu_split_batch : (1 << 20);
+        int W = rows / 64 < LSW_MAX ? rows / 64 : LSW_MAX;
+        const int wcap = 512 / batch > 2 ? 512 / batch : 2;
+        if (W > wcap) W = wcap;
+        if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
+            ProfScope prof(PROF_LU_PANEL, s, 0, 0);
+            TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
+            for (int j = 0; j < jb; ++j)
+                TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info);
+            TRX_LAUNCH((lu_split_scale_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, W, (const int*)piv);
+            TRX_LAUNCH((lu_split_final_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, piv);
+        } else {
+            ProfScope prof(PROF_LU_PANEL, s, 0, 0);
+            TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
+        }
+        // the panel's interchanges on the OTHER columns of this outer block (left: factors of the block's earlier panels; right: columns
+        // of the block still to be factored); the columns outside the block follow when the block is done
+        const int inblock = (Kend - K0) - jb;
+        if (inblock > 0)
+            TRX_LAUNCH((lu_swap_range_kernel<T>), dim3(cdiv_i(inblock, 256), batch), dim3(256), 0, s, A, lda, sA, K0, c0, c0 + jb, Kend, c0, jb, (const int*)piv, n);
+        const int wcols = Kend - (c0 + jb);       // columns of the outer block still to be factored
+        if (wcols > 0) {
+            TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(wcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
+                       at(c0, c0 + jb), lda, sA, wcols);
+            const int rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - c0 - jb, wcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, c0 + jb), lda, sA, one,
+                                   at(c0 + jb, c0 + jb), lda, sA, batch);
+            if (rc) return rc;
+        }
+    }
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+// U rows of the outer block [K0, Kend) for the columns [c_lo, c_hi) right of it (trsm + in-block update per panel), then the rank-kb
+// update of the rows below the block in those columns.
+template <class T>
+int lu_block_update(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, int Kend, int c_lo, int c_hi, int batch) {
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
+    auto at = [&](int r, int c) { return A + (long)r * lda + c; };
+    const int tcols = c_hi - c_lo, kb = Kend - K0;
+    if (tcols <= 0) return TRX_OK;
+    int rc;
+    for (int c0 = K0; c0 < Kend; c0 += NB) {
+        const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
+        TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(tcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
+                   at(c0, c_lo), lda, sA, tcols);
+        const int rin = Kend - (c0 + jb);
+        if (rin > 0) {
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, tcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, c_lo), lda, sA, one, at(c0 + jb, c_lo), lda, sA, batch);
+            if (rc) return rc;
+        }
+    }
+    if (n - Kend > 0) {
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - Kend, tcols, kb, mone, at(Kend, K0), lda, sA, at(K0, c_lo), lda, sA, one, at(Kend, c_lo), lda, sA, batch);
+        if (rc) return rc;
+    }
+    TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
 
@@ -421,65 +529,47 @@ template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
     if (n <= 0 || batch <= 0) return TRX_OK;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
-    auto at = [&](int r, int c) { return A + (long)r * lda + c; };
-    int rc;
-    for (int K0 = 0; K0 < n; K0 += NBO) {
+    const bool look = g_lu_look == 2 ? n > NBO : (g_lu_look == 0 && n >= 1024);
+    LuLane lane;
+    if (look && !lu_lane_checkout(lane)) return TRX_ERR_LAUNCH;
+    int rc = TRX_OK;
+    bool ahead = false;                    // the panels of the current outer block were factored on the side stream (join on e2)
+    for (int K0 = 0; K0 < n && rc == TRX_OK; K0 += NBO) {
         const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
         const int Kend = K0 + kb;
-        for (int c0 = K0; c0 < Kend; c0 += NB) {
-            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-            // few large matrices: row-split panel (see above); needs 2 W ints of the pivot array's unwritten tail
-            const int rows = n - c0;
-            const int split_min = g_lu_split_rows ? g_lu_split_rows : 1024;
-            // workgroups per matrix: about 512 per launch over the batch, at least 64 rows each (a larger batch already supplies
-            // workgroups, but the one-workgroup panel still leaves half of the CUs idle at batch 128: knob lu_split_batch)
-            // measured on MI355X (round 3): the row-split panel also wins at batch 16 and 128 (+1.3 % of the whole layer-solve step each)
-            const int split_batch = g_lu_split_batch ? g_lu_split_batch : (1 << 20);
-            int W = rows / 64 < LSW_MAX ? rows / 64 : LSW_MAX;
-            const int wcap = 512 / batch > 2 ? 512 / batch : 2;
-            if (W > wcap) W = wcap;
-            if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
-                ProfScope prof(PROF_LU_PANEL, s, 0, 0);
-                TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
-                for (int j = 0; j < jb; ++j)
-                    TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info);
-                TRX_LAUNCH((lu_split_scale_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, W, (const int*)piv);
-                TRX_LAUNCH((lu_split_final_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, piv);
-            } else {
-                ProfScope prof(PROF_LU_PANEL, s, 0, 0);
-                TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
-            }
-            if (n - jb > 0)
-                TRX_LAUNCH((lu_swap_kernel<T>), dim3(cdiv_i(n - jb, 256), batch), dim3(256), 0, s, A, lda, sA, n, c0, jb, (const int*)piv, n);
-            const int wcols = Kend - (c0 + jb);       // columns of the outer block still to be factored
-            if (wcols > 0) {
-                TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(wcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
-                           at(c0, c0 + jb), lda, sA, wcols);
-                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - c0 - jb, wcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, c0 + jb), lda, sA, one,
-                             at(c0 + jb, c0 + jb), lda, sA, batch);
-                if (rc) return rc;
-            }
+        if (ahead) {
+            if (hipStreamWaitEvent(s, lane.e2, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+        } else {
+            rc = lu_block_panels<T>(s, A, lda, sA, n, K0, Kend, piv, batch, info);
+            if (rc) break;
         }
+        ahead = false;
+        // the block's interchanges on the columns left and right of it
+        const int outside = K0 + (n - Kend);
+        if (outside > 0)
+            TRX_LAUNCH((lu_swap_range_kernel<T>), dim3(cdiv_i(outside, 256), batch), dim3(256), 0, s, A, lda, sA, 0, K0, Kend, n, K0, kb, (const int*)piv, n);
         const int tcols = n - Kend;
-        if (tcols > 0) {
-            // U rows of the outer block for the trailing columns: four (trsm + in-block update) steps ...
-            for (int c0 = K0; c0 < Kend; c0 += NB) {
-                const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-                TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(tcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
-                           at(c0, Kend), lda, sA, tcols);
-                const int rin = Kend - (c0 + jb);
-                if (rin > 0) {
-                    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, tcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, Kend), lda, sA, one,
-                                 at(c0 + jb, Kend), lda, sA, batch);
-                    if (rc) return rc;
-                }
-            }
-            // ... then ONE rank-kb update of the trailing matrix
-            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, tcols, tcols, kb, mone, at(Kend, K0), lda, sA, at(K0, Kend), lda, sA, one, at(Kend, Kend), lda, sA, batch);
-            if (rc) return rc;
+        if (tcols <= 0) break;
+        const int next_end = (Kend + NBO < n) ? Kend + NBO : n;
+        if (look && next_end < n) {
+            // next block's columns first, then its panels on the side stream under the update of the remaining columns
+            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, Kend, next_end, batch);
+            if (rc) break;
+            if (hipEventRecord(lane.e1, s) != hipSuccess || hipStreamWaitEvent(lane.s2, lane.e1, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+            rc = lu_block_panels<T>(lane.s2, A, lda, sA, n, Kend, next_end, piv, batch, info);
+            if (rc) break;
+            if (hipEventRecord(lane.e2, lane.s2) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
+            ahead = true;
+            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, next_end, n, batch);
+        } else {
+            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, Kend, n, batch);
         }
     }
+    if (look) {
+        if (ahead && rc != TRX_OK) (void)hipStreamWaitEvent(s, lane.e2, 0);       // error path: still join what was queued
+        lu_lane_return(lane);
+    }
+    if (rc) return rc;
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
