@@ -356,7 +356,7 @@ def test_lu_row_split_nan_matrix_stays_in_bounds(backend, where):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
-@pytest.mark.parametrize("n,batch,split", [(530, 2, 0), (777, 1, 128), (1100, 1, 0)])
+@pytest.mark.parametrize("n,batch,split", [(530, 2, 0), (777, 1, 128), (1100, 8, 0)])
 def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
     """Look-ahead LU (knob lu_look; automatic from n = 1024): the next outer block's panels are factored on a side stream under the trailing
     update of the remaining columns, and a block's row interchanges reach the columns outside the block only when the block is done.  The

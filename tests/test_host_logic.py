@@ -127,3 +127,45 @@ def test_bench_profile_bookkeeping(tmp_path, monkeypatch):
     k = {"kernel": "gemm<N,N>", "bound": "mfma", "algorithmic_flops_per_launch": 1e12, "launches": 20}
     out = bench.profile_fracs(k, args, 78.6, steps=2)
     assert abs(out["frac_rocprof"] - (10 * 1e12 / 10.5e-3 / 1e12) / 78.6) < 1e-9 and out["frac_alone"] is None
+
+
+def test_pinned_accumulators_isa():
+    """gemm_big.hip, one-wave-per-SIMD layouts: the fp64 MFMA accumulators are pinned to AGPRs by instruction text (common.hpp TRX_ACC_*,
+    acc_regs.hpp).  That is only sound if the compiler keeps nothing of its own in AGPRs: cross-compile the file (hipcc, gfx950, no GPU
+    needed) and check, per pinned kernel, that every v_accvgpr_* / AGPR-operand instruction of the ISA sits inside an inline-asm region,
+    and that the 8-wave VGPR-form layout uses no AGPR at all."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "torcwa_amd", "csrc", "gemm_big.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "gemm_big.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        text = open(out).read()
+    kernels = re.findall(r"^(_ZN3trx[^:\s]*gemm_big_kernel[^:\s]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) >= 3
+    pinned = vgpr_form = 0
+    for name, body in kernels:
+        in_asm, stray = False, []
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and (re.search(r"\bv_accvgpr", line) or re.search(r"\ba\[?\d", line.split(";")[0])):
+                stray.append(line.strip())
+        if "Lb1EE" in name:                      # PIN = true
+            pinned += 1
+            assert not stray, (name, stray[:5])
+            assert "v_mfma_f64_16x16x4_f64 a[" in body
+        else:
+            vgpr_form += 1
+            assert not stray and "v_accvgpr" not in body, (name, stray[:5])
+            assert "v_mfma_f64_16x16x4_f64 v[" in body
+    assert pinned >= 2 and vgpr_form >= 1

@@ -23,7 +23,7 @@ class rcwa(FieldMixin):
         self.freq = torch.as_tensor(freq, dtype=self._dtype, device=self._device)      # rcwa.py:60
         self.omega = 2 * pi * freq                                                       # rcwa.py:61 (user's freq object)
         self.order = order
-        self.L = L
+        self.L = torch.as_tensor(L, dtype=self._dtype, device=self._device)                  # rcwa.py:62: a complex tensor, not the list
         self.stable_eig_grad = self._b.stable_eig_grad
         self.avoid_Pinv_instability = self._b.avoid_Pinv_instability
         self.max_Pinv_instability = self._b.max_Pinv_instability
