@@ -308,8 +308,12 @@ _TAG_SOURCES = {"gemm": ("gemm.hip", "gemm_big.hip", "mfma.hpp", "common.hpp", "
 _EIG_STAGE = ("apply_window_kernel", "qr_prepare_kernel", "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel")
 
 
+_ROUTE_MEMORY = [False]        # set after the run: torcwa_amd.Engine recorded a mixed-route fallback for this size and switched the sweep to fp64
+
+
 def eig_is_mixed(args, n, chunk):
-    return args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
+    return (args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
+            and not _ROUTE_MEMORY[0])
 
 
 def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
@@ -557,6 +561,7 @@ def main():
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
+    _ROUTE_MEMORY[0] = bool(getattr(engine, "_eig_route_hint", None))
     roof = roofline(engine, args, elapsed, args.steps, n, len(idx) * layers_per_point, chunk) if rank == 0 else None
     if args.host_profile and rank == 0:
         import cProfile
@@ -609,7 +614,10 @@ def main():
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
                        "chunk": int(chunk), "streams": args.streams,
                        "eig_route": ("mixed: fp32 eigendecomposition + fp64 Newton refinement" if eig_is_mixed(args, n, chunk) else
-                                     "fp64 (Hessenberg, multi-shift QR, Schur vectors)") if args.precision == "high" else "fp32 (Hessenberg, multi-shift QR, Schur vectors)",
+                                     ("fp64 (Hessenberg, multi-shift QR, Schur vectors)" +
+                                      (" -- chosen by the engine's route memory after the mixed route fell back on this sweep (clusters of close "
+                                       "eigenvalues beyond the refinement's exact treatment)" if _ROUTE_MEMORY[0] else "")))
+                                    if args.precision == "high" else "fp32 (Hessenberg, multi-shift QR, Schur vectors)",
                        "precision": args.precision, "backend": ("gloo" if EMU else "nccl (RCCL)") if world > 1 else None},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "gathered_points": int(full.shape[0]),
             "numerical_failures": 0, "hbm": mem, "csrc_sha16": csrc_sha16(),

@@ -78,6 +78,11 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   different host threads -- or a complex64 and a complex128 solver of one process -- cannot change each other's route or step count
  *   (torcwa_amd.Engine.eig uses these entry points; tests/test_eig.py::test_eig_opts_two_threads).  The workspace size depends on the route:
  *   size it with trx_eig_ws_bytes_opts and the SAME opts. */
+/* 1 if the calling thread's last trx_eig / trx_eig_opts ran the mixed-precision route and had to redo the batch in fp64 (a matrix with a
+ * cluster of close eigenvalues beyond the refinement's exact treatment: symmetric meta-atoms, dense spectra of large orders), else 0.  The
+ * library is stateless: a caller that solves a SEQUENCE of similar problems (the sweep drivers of torcwa_amd) uses this to ask for the all-fp64
+ * route (opts bits 4-7 = 1) on the following calls instead of paying for the failed attempt every time. */
+int trx_eig_last_fallback(void);
 size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts);
 int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, void* stream, unsigned opts);
 

@@ -423,3 +423,45 @@ def test_eig_opts_two_threads():
     assert not errors, errors
     assert all(1e-12 < r < 1e-6 for r in res[0]), res[0]        # one step: first-order accurate in the fp32 start
     assert all(r < 1e-13 for r in res[1]), res[1]               # three steps: the all-fp64 class
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_eig_route_memory_after_fallback(backend):
+    """A matrix with a ten-fold eigenvalue makes the mixed route redo its batch in fp64 (trx_eig_last_fallback reports it on the calling
+    thread); torcwa_amd.Engine remembers that for the size and asks for the all-fp64 route on the following calls (no second failed attempt),
+    re-probes after EIG_REPROBE calls, and forgets the hint when the probe goes through.  Results are right on every call."""
+    import torch
+    from tests.test_pipeline import make_engine
+    eng = make_engine(backend)
+    n = 40 if backend == "emu" else 300
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    lam = 2.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    lam[:10] = 1.5 - 0.5j
+    hard = torch.from_numpy(((Q * lam[None, :]) @ Q.conj().T)[None].astype(np.complex128)).to(eng.device)
+    easy = torch.from_numpy((rng.standard_normal((1, n, n)) + 1j * rng.standard_normal((1, n, n))).astype(np.complex128)).to(eng.device)
+
+    def solve(A):
+        w, V = eng.eig(A)
+        r = (torch.linalg.norm(A @ V - V * w[:, None, :]) / torch.linalg.norm(A)).item()
+        assert r < 1e-11, r
+
+    eng._eig_route_hint.clear()
+    old_reprobe, be = eng.EIG_REPROBE, get_backend(backend)
+    try:
+        _set_knobs(be, eig_vec=3)                    # mixed wherever n >= 8 (the automatic route needs n >= 256 and batch >= 8)
+        eng.EIG_REPROBE = 3
+        solve(easy)
+        assert not eng._eig_route_hint and eng.lib.eig_last_fallback() == 0
+        solve(hard)                                  # falls back -> remembered
+        assert eng.lib.eig_last_fallback() == 1 and (n, torch.complex128) in eng._eig_route_hint
+        solve(hard)                                  # forced fp64: no mixed attempt, hence no fallback report
+        assert eng.lib.eig_last_fallback() == 0 and (n, torch.complex128) in eng._eig_route_hint
+        solve(easy)                                  # still forced
+        assert (n, torch.complex128) in eng._eig_route_hint
+        solve(easy)                                  # third call since: re-probe on the automatic route, goes through -> hint dropped
+        assert (n, torch.complex128) not in eng._eig_route_hint
+    finally:
+        eng.EIG_REPROBE = old_reprobe
+        eng._eig_route_hint.clear()
+        _set_knobs(be, eig_vec=0)

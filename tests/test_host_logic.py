@@ -169,3 +169,13 @@ def test_pinned_accumulators_isa():
             assert not stray and "v_accvgpr" not in body, (name, stray[:5])
             assert "v_mfma_f64_16x16x4_f64 v[" in body
     assert pinned >= 2 and vgpr_form >= 1
+
+
+def test_generated_accumulator_header_is_current():
+    """torcwa_amd/csrc/acc_regs.hpp is generated (gen_acc_regs.py: one literal instruction text per pinned accumulator); the committed file
+    must be what the generator prints."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "torcwa_amd", "csrc", "gen_acc_regs.py")
+    out = subprocess.run([sys.executable, gen], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "torcwa_amd", "csrc", "acc_regs.hpp")).read()

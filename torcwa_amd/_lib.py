@@ -46,6 +46,7 @@ _SIGS = {
     "trx_prof_get": (c_int, [c_int, c_void_p]),
     "trx_prof_tag_name": (c_char_p, [c_int]),
     "trx_eig": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "trx_eig_last_fallback": (c_int, []),
     "trx_eig_ws_bytes_opts": (c_size_t, [c_int, c_int, c_int, ctypes.c_uint]),
     "trx_eig_opts": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_uint]),
 }

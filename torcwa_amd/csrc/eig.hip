@@ -21,6 +21,7 @@ static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automa
 // call on the calling host thread -- the process-global knobs are only the defaults, so two threads (or a complex64 and a complex128 solver
 // in one process) can no longer overwrite each other's setting between trx_tuning and trx_eig.  -1 = not set (use the knob).
 static thread_local int tl_eig_vec = -1, tl_refine = -1;
+static thread_local int tl_last_fallback = 0;      // the calling thread's last trx_eig: 1 = the mixed route was redone in fp64 (trx_eig_last_fallback)
 static inline int cur_eig_vec() { return tl_eig_vec >= 0 ? tl_eig_vec : g_eig_vec; }
 struct EigCallOpts {
     EigCallOpts(unsigned opts) { const int r = opts & 0xF, v = (opts >> 4) & 0xF; tl_refine = r ? r : -1; tl_eig_vec = v ? v : -1; }
@@ -184,6 +185,7 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
             rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any);
             if (rc) return rc;
+            tl_last_fallback = any ? 1 : 0;
             if (!any) return finish_vectors<T>(s, B, n, batch, (cx<T>*)V);
             // some matrix has a cluster of more than two eigenvalues, an fp32 result that is too far off, or a singular V: redo the batch
             // in fp64 (A is still the balanced input, the scaling D is kept)
@@ -306,6 +308,8 @@ extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {
     return dtype == TRX_C128 ? trx::eig_ws_bytes_t<double>(n, batch) : trx::eig_ws_bytes_t<float>(n, batch);
 }
 
+extern "C" int trx_eig_last_fallback(void) { return trx::tl_last_fallback; }
+
 extern "C" size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts) {
     if ((opts & 0xF) > 4 || ((opts >> 4) & 0xF) > 3 || (opts >> 8)) return 0;
     trx::EigCallOpts guard(opts);
@@ -324,5 +328,6 @@ extern "C" int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, i
     if (dtype != TRX_C64 && dtype != TRX_C128) return TRX_ERR_DTYPE;
     if (ws_bytes < trx_eig_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
     hipStream_t s = trx::api_stream(stream);
+    trx::tl_last_fallback = 0;
     return dtype == TRX_C128 ? trx::eig_t<double>(s, A, w, V, n, batch, info, ws) : trx::eig_t<float>(s, A, w, V, n, batch, info, ws);
 }

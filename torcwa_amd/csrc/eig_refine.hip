@@ -412,6 +412,15 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.d0, R.eoff, R.lmax);
         TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<T>*)R.G, (const cx<T>*)w, n, (const T*)R.eoff, (const T*)R.lmax, R.partner, R.flags);
         TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), 0, s, (const cx<T>*)R.G, n, w, (const int*)R.partner, R.clus, (RefineClusters<T>*)R.pairX, R.flags);
+        if (it == 0) {
+            // A matrix the scheme cannot certify (far-off start, a cluster beyond the exact treatment, singular V) is known after the FIRST
+            // scan, and the whole batch is then redone by the all-fp64 pipeline: stop here instead of finishing Newton steps whose result is
+            // thrown away (symmetric meta-atoms and the dense spectra of large orders raise the flag for a third of a sweep: configs 3, 4).
+            TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
+            if (hipMemcpyAsync(host_any, R.flags + batch, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
+            if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
+            if (*host_any && !getenv("TRX_EIG_DEBUG")) return TRX_OK;
+        }
         TRX_LAUNCH((refine_build_clusters_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus, (const RefineClusters<T>*)R.pairX);
         TRX_LAUNCH((refine_build_inplace_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus);
         rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Vc, n, nn, R.G, n, nn, zero, Vn, n, nn, batch); if (rc) return rc;
