@@ -358,10 +358,10 @@ def test_lu_row_split_nan_matrix_stays_in_bounds(backend, where):
 @pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
 @pytest.mark.parametrize("n,batch,split", [(530, 2, 0), (777, 1, 128), (1100, 8, 0)])
 def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
-    """Look-ahead LU (knob lu_look; automatic from n = 1024): the next outer block's panels are factored on a side stream under the trailing
+    """Look-ahead LU (knob lu_look = 2; off by default): the next outer block's panels are factored on a side stream under the trailing
     update of the remaining columns, and a block's row interchanges reach the columns outside the block only when the block is done.  The
     panels see the same data in the same order, so pivots AND factors must equal the sequential schedule bit for bit (n = 530 / 777: two /
-    three outer blocks + a short tail with the schedule forced on; n = 1100: the automatic regime)."""
+    three outer blocks + a short tail; n = 1100: five blocks at batch 8)."""
     be = get_backend(backend)
     if backend == "emu" and n > 800:
         pytest.skip("emulator: the two smaller sizes cover the schedule")
@@ -369,7 +369,7 @@ def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
     A[0, :, 3] *= 1e-3
     B = crand((batch, n, 5), dtype)
     res = []
-    for look in (1, 2 if n < 1024 else 0):          # 1: off; 2: forced on; 0: automatic
+    for look in (1, 2):          # 1: off; 2: on
         assert be.lib.tuning(b"lu_look", look) == 0 and be.lib.tuning(b"lu_split", split) == 0
         try:
             dA, dB = be.dev(A), be.dev(B)

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 constexpr int NBO = 8 * NB;
 
 static int lu_look_env() { const char* e = getenv("TRX_LU_LOOK"); return e ? atoi(e) : 0; }
-static int g_lu_look = lu_look_env();         // trx_tuning("lu_look", v): 0 automatic (look-ahead for n >= 1024 and batch >= 8), 1 off, 2 always (tests)
+static int g_lu_look = lu_look_env();         // trx_tuning("lu_look", v): 0 / 1 off (default: measured a wash), 2 = look-ahead whenever there is more than one outer block
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
@@ -529,9 +529,10 @@ template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
     if (n <= 0 || batch <= 0) return TRX_OK;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    // measured on MI355X (profiles/r04_ab/r4_lu_look.txt): 3955 -> 3914 ms per 128-point step (n = 1922), nothing at batch 16, and a single
-    // n = 5202 matrix (config 5) 1 % slower -- its row-split panels already use the whole chip: automatic from batch 8
-    const bool look = g_lu_look == 2 ? n > NBO : (g_lu_look == 0 && n >= 1024 && batch >= 8);
+    // Measured on MI355X (profiles/r04_ab/r4_lu_look.txt, r04 evidence runs): 3955 -> 3914 ms per 128-point step (n = 1922) without the
+    // bench's event sampling and 3971 -> 3974 ms with it, nothing at batch 16, a single n = 5202 matrix 1 % slower -- and the large-tile GEMM it
+    // overlaps drops from 0.86 to 0.83 of the matrix peak in situ.  A wash: opt-in (knob lu_look = 2), the sequential schedule is the default.
+    const bool look = g_lu_look == 2 && n > NBO;
     LuLane lane;
     if (look && !lu_lane_checkout(lane)) return TRX_ERR_LAUNCH;
     int rc = TRX_OK;
