@@ -17,7 +17,8 @@ L.prof_enable(1)
 for cfgs in (sys.argv[3].split(',') if len(sys.argv) > 3 else "0,2,3,4".split(',')):
     parts = [int(v) for v in cfgs.split(':')] + [0, 0]
     cfg, xcd, dbg = parts[0], parts[1], parts[2]
-    assert L.tuning(b"invit_dbg", dbg) == 0
+    if dbg:      # the skip bits exist only in a -DTRX_INVIT_DEBUG build of eig_invit.hip (they change results: not a knob of the release library)
+        assert L.tuning(b"invit_dbg", dbg) == 0, "rebuild libtrx with -DTRX_INVIT_DEBUG for the timing-experiment bits"
     assert L.tuning(b"invit_cfg", cfg) == 0 and L.tuning(b"eig_vec", 2) == 0 and L.tuning(b"invit_xcd", xcd) == 0
     A = A0.clone()
     L.prof_reset()
