@@ -98,6 +98,7 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *   "qr_nibble"   0-100 LITERAL percentage, default 100 (TRX_QR_NIBBLE): an AED that deflated less than this share of its window is
  *                       followed by a sweep in the same outer iteration; 0 switches that sweep off.  No automatic value.
  *   "qr_moves"    0-64  LITERAL bound, default 12 (TRX_QR_MOVES): undeflatable eigenvalues an AED moves out of the way; 0 = no reordering.
+ *   "qr_rotb"     1 = the in-LDS Schur solver of the AED broadcasts each rotation with ds_bpermute (round-3 code); default: v_readlane (TRX_QR_ROTB)
  *   "slab_spw"    1, 2, 4  strips per wave of the off-window update with static strips (TRX_SLAB_SPW)     auto: 4 (batch >= 64), else 2
  *   "slab_dyn"    1 static / 2 dynamically claimed strips (TRX_SLAB_DYN)              auto: dynamic for groups of >= 16 matrices
  *   "slab_wgs"    32-4096 workgroups per dynamic off-window launch (TRX_SLAB_WGS)     auto: 512
