@@ -375,6 +375,7 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 
 // direct global -> LDS load (torcwa_amd/csrc/common.hpp): the emulator copies at once, so the wait is empty
 #define TRX_LDS_DMA16(gsrc_lane, lds_wave_base) std::memcpy((char*)(lds_wave_base) + 16 * (threadIdx.x & 63), (const void*)(gsrc_lane), 16)
+#define TRX_LDS_DMA16_S(sbase, voff32, lds_wave_base) std::memcpy((char*)(lds_wave_base) + 16 * (threadIdx.x & 63), (const char*)(sbase) + (unsigned)(voff32), 16)
 #define TRX_WAIT_VMCNT(n) ((void)0)
 #define TRX_WAIT_VMCNT_IMM(expr) ((void)0)
 // register-pinned MFMA accumulators of the product (common.hpp): an ordinary array here

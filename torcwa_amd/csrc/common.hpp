@@ -23,6 +23,11 @@
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"((const void*)(gsrc_lane)),   \
                  "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_wave_base)))                                    \
                  : "memory", "m0")
+// The same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit vector address arithmetic per load.
+#define TRX_LDS_DMA16_S(sbase, voff32, lds_wave_base)                                                                                 \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(voff32)), "s"((const void*)(sbase)),   \
+                 "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_wave_base)))                                               \
+                 : "memory", "m0")
 #define TRX_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // the same with any constant expression 0 .. 63 (gfx9 encodes a 6-bit vmcnt)
 #define TRX_WAIT_VMCNT_IMM(expr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(expr) : "memory")

@@ -425,7 +425,9 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
         int bm = 0, bn = 0;
         const int big = gemm_big_cfg();
         if (big) gemm_big_tile(big, &bm, &bn);
-        if (big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64) {
+        // (its direct loads address an operand with 32-bit BYTE offsets from a scalar base: the operand's extent must stay below 4 GiB)
+        const long exA = (long)(opA == TRX_OP_N ? m : k) * lda, exB = (long)(opB == TRX_OP_N ? k : n) * ldb;
+        if (big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64 && exA < (1L << 28) && exB < (1L << 28)) {
             const int rm = (m % bm) <= 32 ? m % bm : 0, rn = (n % bn) <= 32 ? n % bn : 0;
             const int mm = m - rm, nm = n - rn;
             int rc = gemm_big(s, big, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
     // ---- what this lane fetches: chunks wave, wave + 4, ... of a stage; the element follows from the LDS slot p = 64 c' + lane
     const cx<T>* gsrc[NI];        // address of the lane's element at k = 0 (clamped row / column)
     int gkk[NI];                  // its k offset inside a slab (pad slots and padding loads re-read offset 0)
+    unsigned goff[NI];            // byte offset of the lane's element of slab 0 from the operand's base (full slabs: base + slab stride + goff)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = wave + NW * i;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
             const int gr = m0 + row < m ? m0 + row : m - 1;
             gsrc[i] = A_KC ? A + (long)gr * lda : A + gr;
             gkk[i] = kk;
+            goff[i] = (unsigned)(16u * (A_KC ? (unsigned)gr * (unsigned)lda + (unsigned)kk : (unsigned)kk * (unsigned)lda + (unsigned)gr));
         } else if (c < CA + CB) {
             const int p = 64 * (c - CA) + lane;
             int col, kk;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
             const int gc = n0 + col < n ? n0 + col : n - 1;
             gsrc[i] = B_KC ? B + (long)gc * ldb : B + gc;
             gkk[i] = kk;
+            goff[i] = (unsigned)(16u * (B_KC ? (unsigned)gc * (unsigned)ldb + (unsigned)kk : (unsigned)kk * (unsigned)ldb + (unsigned)gc));
         } else {
-            gsrc[i] = A; gkk[i] = 0;
+            gsrc[i] = A; gkk[i] = 0; goff[i] = 0;
         }
     }
     const int arow0 = 16 * QTM * (wave % WM), bcol0 = 16 * QTN * (wave / WM);
@@ -143,12 +146,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
             fb[set][f - QTM][0] = br; fb[set][f - QTM][1] = bi; fb[set][f - QTM][2] = br + bi;
         }
     };
+    // A load of a FULL slab (all 8 k-values inside the matrix) needs no clamp: its address is a wave-uniform base -- operand + slab stride,
+    // scalar arithmetic -- plus the lane's fixed 32-bit byte offset (one matrix spans less than 4 GiB: checked by the caller), so the issue
+    // costs no vector instruction besides the load.  The partial slab at the end of K and the slabs the ring prefetches beyond it take the
+    // clamped path (a 64-bit multiply-add per lane).
     auto issue_one = [&](int i, int slab) __attribute__((always_inline)) {
         const int c = wave + NW * i;                                          // wave-uniform
-        const int kg = slab * QBK + gkk[i] < k ? slab * QBK + gkk[i] : k - 1; // clamped: finite data, masked at the A fragment
-        const long step = c < CA ? (A_KC ? 1 : lda) : (c < CA + CB ? (B_KC ? 1 : ldb) : 0);       // padding load: re-reads A[0]
         cx<T>* dst = c < CA + CB ? ring + (slab % QST) * STG + 64 * c : scratch;
-        TRX_LDS_DMA16(gsrc[i] + (long)kg * step, dst);
+        if (slab * QBK + QBK <= k) {
+            const bool isA = c < CA, pad = c >= CA + CB;
+            const long sstep = pad ? 0 : (isA ? (A_KC ? 1 : lda) : (B_KC ? 1 : ldb));
+            const cx<T>* base = (isA || pad ? A : B) + (long)slab * QBK * sstep;
+            TRX_LDS_DMA16_S(base, goff[i], dst);
+        } else {
+            const int kg = slab * QBK + gkk[i] < k ? slab * QBK + gkk[i] : k - 1; // clamped: finite data, masked at the A fragment
+            const long step = c < CA ? (A_KC ? 1 : lda) : (c < CA + CB ? (B_KC ? 1 : ldb) : 0);       // padding load: re-reads A[0]
+            TRX_LDS_DMA16(gsrc[i] + (long)kg * step, dst);
+        }
     };
 #pragma unroll
     for (int sl = 0; sl < QST - 1; ++sl)
