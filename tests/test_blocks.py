@@ -384,3 +384,37 @@ def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     X = np.linalg.solve(A.astype(np.complex128), B.astype(np.complex128))
     assert np.abs(res[1][1] - X).max() / np.abs(X).max() < (1e-10 if dtype == np.complex128 else 5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opA,opB", [(0, 0), (2, 0), (0, 2)])
+def test_gemm_large_tile_hot_shape_gpu(opA, opB):
+    """The hot shape of the bench step (1922 = 15 x 128 + 2 = 20 x 96 + 2: both peels, 241 slabs with a K tail of 2) through the default
+    large-tile kernel against the 64 x 64 kernel of gemm.hip (knob gemm_big = 4) and, on a row / column sample, against numpy."""
+    be = get_backend("gpu")
+    import torch
+    m = n = k = 1922
+    batch = 3
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.randn(batch, m, k, dtype=torch.complex128, device="cuda", generator=g)
+    B = torch.randn(batch, k, n, dtype=torch.complex128, device="cuda", generator=g)
+    C0 = torch.randn(batch, m, n, dtype=torch.complex128, device="cuda", generator=g)
+    al, bt = np.array([0.7 - 0.2j]), np.array([-0.3 + 0.5j])
+    outs = []
+    for knob in (0, 4):
+        C = C0.clone()
+        try:
+            assert be.lib.tuning(b"gemm_big", knob) == 0
+            rc = be.lib.gemm(1, opA, opB, m, n, k, al.ctypes.data, A.data_ptr(), k, m * k, B.data_ptr(), n, k * n, bt.ctypes.data, C.data_ptr(), n, m * n,
+                             batch, be.stream)
+        finally:
+            be.lib.tuning(b"gemm_big", 0)
+        assert rc == 0
+        outs.append(C)
+    torch.cuda.synchronize()
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) / scale < 1e-12
+    f = {0: lambda x: x, 2: lambda x: x.conj().transpose(1, 2)}
+    rows = torch.tensor([0, 1, 127, 128, 1919, 1920, 1921], device="cuda")
+    ref = al[0] * (f[opA](A)[:, rows, :] @ f[opB](B)) + bt[0] * C0[:, rows, :]
+    assert float((outs[0][:, rows, :] - ref).abs().max()) / scale < 1e-12

@@ -38,6 +38,7 @@ class Engine:
         self.check_info = True
         self._fail_acc = {}            # per host thread: device-side count of non-zero info entries seen while check_info is False
         self._eig_route_hint = {}      # (n, dtype) -> [1, calls since]: sizes whose mixed-precision attempt fell back to fp64 (see eig())
+        self._hint_lock = threading.Lock()          # the sweep drivers may call eig() from several host threads
 
     # -- helpers ---------------------------------------------------------------------------------------
     @property
@@ -161,13 +162,14 @@ class Engine:
         # paying for the failed attempt every time (measured on MI355X: config 4 at chunk 256 17.6 -> 33.7 layer-solves/s, config 3
         # 2.3 -> 3.9).  Every EIG_REPROBE-th such call tries the automatic route again.
         key = (int(A.shape[-1]), A.dtype)
-        hint = self._eig_route_hint.get(key)
         forced = False
-        if hint is not None and os.environ.get("TRX_EIG_VEC", "0") == "0":
-            hint[1] += 1
-            if hint[1] % self.EIG_REPROBE != 0:
-                opts |= 1 << 4
-                forced = True
+        with self._hint_lock:
+            hint = self._eig_route_hint.get(key)
+            if hint is not None and os.environ.get("TRX_EIG_VEC", "0") == "0":
+                hint[1] += 1
+                if hint[1] % self.EIG_REPROBE != 0:
+                    opts |= 1 << 4
+                    forced = True
         A = self._c(A) if destroy else A.clone()
         B, n, _ = A.shape
         dt = A.dtype
@@ -178,10 +180,12 @@ class Engine:
         ws = self._ws(nws)
         self.lib.check(self.lib.eig_opts(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream, opts))
         if not forced:
-            if self.lib.eig_last_fallback():
-                self._eig_route_hint.setdefault(key, [1, 0])
-            elif hint is not None:
-                del self._eig_route_hint[key]           # the re-probe went through: back to the automatic route
+            fell_back = bool(self.lib.eig_last_fallback())          # thread-local in the library: this thread's call
+            with self._hint_lock:
+                if fell_back:
+                    self._eig_route_hint.setdefault(key, [1, 0])
+                elif hint is not None:
+                    self._eig_route_hint.pop(key, None)     # the re-probe went through: back to the automatic route
         self._info(info, "eig")
         return w, V
 
