@@ -363,8 +363,8 @@ def test_lu_look_ahead_is_bit_identical(backend, dtype, n, batch, split):
     panels see the same data in the same order, so pivots AND factors must equal the sequential schedule bit for bit (n = 530 / 777: two /
     three outer blocks + a short tail; n = 1100: five blocks at batch 8)."""
     be = get_backend(backend)
-    if backend == "emu" and n > 800:
-        pytest.skip("emulator: the two smaller sizes cover the schedule")
+    if backend == "emu" and (n > 800 or dtype == np.complex64):
+        pytest.skip("emulator: the two smaller sizes in complex128 cover the schedule (the CPU suite stays within minutes)")
     A = crand((batch, n, n), dtype)
     A[0, :, 3] *= 1e-3
     B = crand((batch, n, 5), dtype)
