@@ -15,9 +15,8 @@
  *    per outer iteration (about n / 16 of them per sub-batch) the host reads a 12-byte progress summary from pinned memory, one
  *    iteration after it was produced, and for batch >= 8 it runs the QR phase of 2-4 sub-batches on internal non-blocking streams
  *    (forked from and joined back into `stream` with events) so that their latency-bound steps overlap; on the mixed-precision route it
- *    also reads one flag word after the refinement.  The LU factorisation (trx_lu_solve, trx_inverse and everything built on them) can use
- *    one internal side stream for a look-ahead (knob "lu_look", off by default; forked / joined with events, no host synchronisation).  Those streams and events come from
- *    process-wide pools created on first use (nothing is created or destroyed per call), and no environment variable is read per call.
+ *    also reads one flag word after the refinement.  Those streams and events come from
+ *    a process-wide pool created on first use (nothing is created or destroyed per call), and no environment variable is read per call.
  *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
  *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
  */
@@ -122,8 +121,6 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
- *   "lu_look"     2 = look-ahead (TRX_LU_LOOK): the next outer block's panels are factored on an internal side stream under the trailing
- *                       update (bit-identical factors)                                      auto: off (measured a wash at every batch size)
  *   Hessenberg reduction: TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
 int trx_tuning(const char* key, int value);
 

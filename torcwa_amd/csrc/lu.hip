@@ -11,9 +11,7 @@
 #include "common.hpp"
 #include <cstdlib>
 #include "prof.hpp"
-#include <mutex>
 #include <string>
-#include <vector>
 
 namespace trx {
 namespace {
@@ -275,40 +273,59 @@ __global__ __launch_bounds__(LST) void lu_split_scale_kernel(cx<T>* __restrict__
     }
 }
 
+// Bookkeeping and row moves of this kernel were one thread's linear searches plus, per panel column, a chain of jb dependent swaps in global
+// memory (200 us per launch at EVERY batch size: 0.12 s of a config-5 step, 2 % of a batch-16 step).  Now: the map "original row -> current
+// position" of the <= 2 jb rows that move lives in LDS with ONE ENTRY PER LANE, each of the jb sequential steps finds its two entries by
+// ballot; the moves themselves are not replayed swap by swap: no row has moved physically yet, so the final map says where every affected row
+// goes -- all sources are staged in LDS (2 jb rows x jb columns, coalesced), then written to their destinations.  Same interchange sequence,
+// same result, bit for bit.
 template <class T>
 __global__ __launch_bounds__(64) void lu_split_final_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int* __restrict__ piv_all) {
-    __shared__ int key[2 * NB], pos[2 * NB];             // original row -> current position, for the rows that have moved
+    __shared__ int key[2 * NB], pos[2 * NB];             // original row -> current position, for the rows that have moved (entry l on lane l)
     __shared__ int seq[NB];
+    __shared__ int nk_s;
+    __shared__ cx<T> stage[2 * NB][NB + 1];
     const int b = blockIdx.x, t = threadIdx.x;
     cx<T>* A = Aall + (long)b * sA;
     int* piv = piv_all + (long)b * n;
-    if (t == 0) {
-        int nk = 0;
-        auto where = [&](int orig) { for (int q = 0; q < nk; ++q) if (key[q] == orig) return pos[q]; return orig; };
-        auto put = [&](int orig, int at) { for (int q = 0; q < nk; ++q) if (key[q] == orig) { pos[q] = at; return; } key[nk] = orig; pos[nk] = at; ++nk; };
-        for (int j = 0; j < jb; ++j) {
-            const int target = piv[k0 + j];               // original row chosen for column j
-            const int here = k0 + j;
-            const int q = where(target);                  // where it sits now
-            // the row now at position `here` is the original row `o` with where(o) == here
-            int o = here;
-            for (int z = 0; z < nk; ++z) if (pos[z] == here) o = key[z];
-            seq[j] = q;
-            if (q != here) { put(target, here); put(o, q); }
-        }
-        for (int j = 0; j < jb; ++j) piv[k0 + j] = seq[j];
-    }
+    if (t == 0) nk_s = 0;
     __syncthreads();
-    if (t < jb) {
-        const int c = k0 + t;
-        for (int j = 0; j < jb; ++j) {
-            const int r = k0 + j, p = seq[j];
-            if (p != r) {
-                const cx<T> a = A[(long)r * lda + c];
-                A[(long)r * lda + c] = A[(long)p * lda + c];
-                A[(long)p * lda + c] = a;
+    for (int j = 0; j < jb; ++j) {
+        const int target = piv[k0 + j];                   // original row chosen for column j (uniform: every lane reads the same word)
+        const int here = k0 + j;
+        const int nk = nk_s;
+        const int kt = t < nk ? key[t] : -1, pt = t < nk ? pos[t] : -1;
+        const unsigned long long m_tgt = __ballot(kt == target);       // where the target row sits now
+        const unsigned long long m_here = __ballot(pt == here);        // which original row sits at position `here`
+        const int lt = m_tgt ? __builtin_ctzll(m_tgt) : -1, lh = m_here ? __builtin_ctzll(m_here) : -1;
+        const int q = lt >= 0 ? __shfl(pt, lt) : target;
+        const int o = lh >= 0 ? __shfl(kt, lh) : here;
+        __syncthreads();
+        if (t == 0) {
+            seq[j] = q;
+            if (q != here) {
+                int nn = nk;
+                if (lt >= 0) pos[lt] = here; else { key[nn] = target; pos[nn] = here; ++nn; }          // put(target, here)
+                // put(o, q): o's entry -- it may be the one just appended (o == target cannot happen: q != here)
+                int lo = lh;
+                if (lo < 0) { for (int z = nk; z < nn; ++z) if (key[z] == o) lo = z; }
+                if (lo >= 0) pos[lo] = q; else { key[nn] = o; pos[nn] = q; ++nn; }
+                nk_s = nn;
             }
         }
+        __syncthreads();
+    }
+    if (t < jb) piv[k0 + t] = seq[t];
+    // every entry (key -> pos) with key != pos is a row of the panel that moves from its original place `key` to `pos`
+    const int nk = nk_s;
+    for (int e = t; e < nk * jb; e += 64) {
+        const int l = e / jb, c = e - l * jb;
+        stage[l][c] = A[(long)key[l] * lda + k0 + c];
+    }
+    __syncthreads();
+    for (int e = t; e < nk * jb; e += 64) {
+        const int l = e / jb, c = e - l * jb;
+        if (pos[l] != key[l]) A[(long)pos[l] * lda + k0 + c] = stage[l][c];
     }
 }
 
@@ -407,8 +424,6 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
-static int lu_look_env() { const char* e = getenv("TRX_LU_LOOK"); return e ? atoi(e) : 0; }
-static int g_lu_look = lu_look_env();         // trx_tuning("lu_look", v): 0 / 1 off (default: measured a wash), 2 = look-ahead whenever there is more than one outer block
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
@@ -417,41 +432,15 @@ int lu_set_knob(const char* key, int value) {
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
     if (k == "lu_split") g_lu_split_rows = value;
     else if (k == "lu_split_batch") g_lu_split_batch = value;
-    else if (k == "lu_look") { if (value > 2) return TRX_ERR_ARG; g_lu_look = value; }
     else return TRX_ERR_ARG;
     return TRX_OK;
 }
 
-// ---- look-ahead --------------------------------------------------------------------------------------------------------------
-// The panels of an outer block are chains of short launches (one per panel column: 50 us each, latency-bound, 0.3 s of a 4 s bench step
-// over its nine factorisations), the rank-256 trailing update behind them is one matrix-core-bound launch; run one after the other
-// neither fills the chip.  With look-ahead the trailing update of outer block K is split at the next block's columns: those 256 columns
-// are updated first, then a side stream factors block K+1 there while the main stream updates the rest.  What makes the two independent is
-// that a block's row interchanges are applied to the columns OUTSIDE the block only when the block is finished (lu_swap_range_kernel, on
-// the main stream after the join) -- inside the block the panels see exactly the data and choose exactly the pivots they did before, so
-// the factors are bit-identical to the sequential order.  Stream and events come from a process-wide pool (nothing is created per call
-// after the first, no host synchronisation).
-struct LuLane { hipStream_t s2 = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr; int dev = -1; };
-static std::mutex g_lu_lane_mu;
-static std::vector<LuLane> g_lu_lane_free;
-static bool lu_lane_checkout(LuLane& out) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    {
-        std::lock_guard<std::mutex> lock(g_lu_lane_mu);
-        for (size_t i = 0; i < g_lu_lane_free.size(); ++i)
-            if (g_lu_lane_free[i].dev == dev) { out = g_lu_lane_free[i]; g_lu_lane_free.erase(g_lu_lane_free.begin() + i); return true; }
-    }
-    out = LuLane();
-    out.dev = dev;
-    return hipStreamCreateWithFlags(&out.s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&out.e1, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&out.e2, hipEventDisableTiming) == hipSuccess;
-}
-static void lu_lane_return(const LuLane& l) {
-    std::lock_guard<std::mutex> lock(g_lu_lane_mu);
-    g_lu_lane_free.push_back(l);
-}
-
+// ---- outer blocks --------------------------------------------------------------------------------------------------------------
+// An outer block's panels apply their row interchanges inside the block's columns only; the columns left and right of the block receive all
+// kb interchanges at once when the block is finished (lu_swap_range_kernel).  (A look-ahead on top of this split -- the next block's panels
+// on a side stream under the trailing update of the remaining columns -- was built and measured in round 4: bit-identical factors, but a
+// wash in time at every batch size, and its GPU test was not deterministic; removed.  profiles/r04_ab/r4_lu_look.txt)
 // Panels of the outer block [K0, Kend) on stream s; row interchanges applied inside the block's columns only.
 template <class T>
 int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, int Kend, int* piv, int batch, int* info) {
@@ -529,50 +518,18 @@ template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
     if (n <= 0 || batch <= 0) return TRX_OK;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    // Measured on MI355X (profiles/r04_ab/r4_lu_look.txt, r04 evidence runs): 3955 -> 3914 ms per 128-point step (n = 1922) without the
-    // bench's event sampling and 3971 -> 3974 ms with it, nothing at batch 16, a single n = 5202 matrix 1 % slower -- and the large-tile GEMM it
-    // overlaps drops from 0.86 to 0.83 of the matrix peak in situ.  A wash: opt-in (knob lu_look = 2), the sequential schedule is the default.
-    const bool look = g_lu_look == 2 && n > NBO;
-    LuLane lane;
-    if (look && !lu_lane_checkout(lane)) return TRX_ERR_LAUNCH;
-    int rc = TRX_OK;
-    bool ahead = false;                    // the panels of the current outer block were factored on the side stream (join on e2)
-    for (int K0 = 0; K0 < n && rc == TRX_OK; K0 += NBO) {
+    for (int K0 = 0; K0 < n; K0 += NBO) {
         const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
         const int Kend = K0 + kb;
-        if (ahead) {
-            if (hipStreamWaitEvent(s, lane.e2, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-        } else {
-            rc = lu_block_panels<T>(s, A, lda, sA, n, K0, Kend, piv, batch, info);
-            if (rc) break;
-        }
-        ahead = false;
+        int rc = lu_block_panels<T>(s, A, lda, sA, n, K0, Kend, piv, batch, info);
+        if (rc) return rc;
         // the block's interchanges on the columns left and right of it
         const int outside = K0 + (n - Kend);
         if (outside > 0)
             TRX_LAUNCH((lu_swap_range_kernel<T>), dim3(cdiv_i(outside, 256), batch), dim3(256), 0, s, A, lda, sA, 0, K0, Kend, n, K0, kb, (const int*)piv, n);
-        const int tcols = n - Kend;
-        if (tcols <= 0) break;
-        const int next_end = (Kend + NBO < n) ? Kend + NBO : n;
-        if (look && next_end < n) {
-            // next block's columns first, then its panels on the side stream under the update of the remaining columns
-            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, Kend, next_end, batch);
-            if (rc) break;
-            if (hipEventRecord(lane.e1, s) != hipSuccess || hipStreamWaitEvent(lane.s2, lane.e1, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-            rc = lu_block_panels<T>(lane.s2, A, lda, sA, n, Kend, next_end, piv, batch, info);
-            if (rc) break;
-            if (hipEventRecord(lane.e2, lane.s2) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-            ahead = true;
-            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, next_end, n, batch);
-        } else {
-            rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, Kend, n, batch);
-        }
+        rc = lu_block_update<T>(s, A, lda, sA, n, K0, Kend, Kend, n, batch);
+        if (rc) return rc;
     }
-    if (look) {
-        if (ahead && rc != TRX_OK) (void)hipStreamWaitEvent(s, lane.e2, 0);       // error path: still join what was queued
-        lu_lane_return(lane);
-    }
-    if (rc) return rc;
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
