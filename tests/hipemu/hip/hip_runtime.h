@@ -378,12 +378,6 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 #define TRX_LDS_DMA16_S(sbase, voff32, lds_wave_base) std::memcpy((char*)(lds_wave_base) + 16 * (threadIdx.x & 63), (const char*)(sbase) + (unsigned)(voff32), 16)
 #define TRX_WAIT_VMCNT(n) ((void)0)
 #define TRX_WAIT_VMCNT_IMM(expr) ((void)0)
-// register-pinned MFMA accumulators of the product (common.hpp): an ordinary array here
-#define TRX_ACC_DECL(count) hipemu_f64x4 trx_acc__[count]
-#define TRX_ACC_MFMA(IDX, a, b) (trx_acc__[IDX] = __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), trx_acc__[IDX], 0, 0, 0))
-#define TRX_ACC_ZERO(IDX) (trx_acc__[IDX] = hipemu_f64x4{0, 0, 0, 0})
-#define TRX_ACC_READ(IDX, R, out) ((out) = trx_acc__[IDX][R])
-#define TRX_ACC_DRAIN() ((void)0)
 
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 namespace hipemu {

@@ -20,12 +20,9 @@ def crand(shape, dtype):
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 2e-5)])
 @pytest.mark.parametrize("opA,opB", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (2, 2)])
 @pytest.mark.parametrize("m,n,k", [(70, 67, 37), (70, 20, 37), (20, 150, 37), (32, 129, 64), (100, 32, 16), (65, 130, 3), (130, 70, 100)])
-@pytest.mark.parametrize("ring", [0, 1])
-def test_gemm(backend, dtype, tol, opA, opB, m, n, k, ring):
-    """(70,67,37): general 64x64 tile with ragged edges (fp64: the direct-to-LDS ring, K tail masked, ring wrap-around); n <= 32: the 64x32
-    tile; m <= 32: the 32x128 tile; (65,130,3): fewer K slabs than ring stages; (130,70,100): several tiles and 13 slabs."""
-    if ring and (dtype != np.complex128 or n <= 32 or m <= 32):
-        pytest.skip("the direct-to-LDS ring serves the fp64 general tile only")
+def test_gemm(backend, dtype, tol, opA, opB, m, n, k):
+    """(70,67,37): general 64x64 tile with ragged edges; n <= 32: the 64x32 tile; m <= 32: the 32x128 tile; (65,130,3): a single partial
+    K slab; (130,70,100): several tiles and slabs."""
     be = get_backend(backend)
     batch = 2
     A = crand((batch, m, k) if opA == 0 else (batch, k, m), dtype)
@@ -33,12 +30,8 @@ def test_gemm(backend, dtype, tol, opA, opB, m, n, k, ring):
     C0 = crand((batch, m, n), dtype)
     al, bt = np.array([0.7 - 0.2j], dtype=dtype), np.array([-0.3 + 0.5j], dtype=dtype)
     dA, dB, dC = be.dev(A), be.dev(B), be.dev(C0)
-    try:
-        assert be.lib.tuning(b"gemm_dma", ring) == 0
-        rc = be.lib.gemm(dtcode(dtype), opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
-                         be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
-    finally:
-        be.lib.tuning(b"gemm_dma", 0)
+    rc = be.lib.gemm(dtcode(dtype), opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
+                     be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
     assert rc == 0
     f = {0: lambda x: x, 1: lambda x: x.transpose(0, 2, 1), 2: lambda x: x.conj().transpose(0, 2, 1)}
     ref = al[0] * (f[opA](A).astype(np.complex128) @ f[opB](B).astype(np.complex128)) + bt[0] * C0
@@ -46,16 +39,14 @@ def test_gemm(backend, dtype, tol, opA, opB, m, n, k, ring):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("opA,opB,m,n,k,beta", [
-    (0, 0, 2 * 160 + 2, 2 * 128 + 2, 77, 0.0),      # remainders of 2 rows / columns against every tile: peeled (cfg 1: 322 = 3 x 96 + 34, in-tile)
+    (0, 0, 2 * 128 + 2, 2 * 96 + 2, 77, 0.0),       # remainders of 2 rows / columns: peeled off for the narrow tiles
     (0, 2, 2 * 128 + 40, 2 * 96 + 50, 64, 1.0),     # remainders above 32: ragged large tiles; beta != 0; K a multiple of the slab
     (2, 0, 330, 259, 131, 1.0),                     # A conjugate-transposed; 17 slabs with a K tail of 3
     (1, 1, 321, 270, 70, 0.0),
 ])
-def test_gemm_large_tile(backend, cfg, opA, opB, m, n, k, beta):
-    """gemm_big.hip (knob gemm_big = tile configuration): one wave per SIMD, register-pinned accumulators, direct-to-LDS ring; against numpy,
-    with the thin-remainder peel of gemm.hip in play."""
+def test_gemm_large_tile(backend, opA, opB, m, n, k, beta):
+    """gemm_big.hip (128 x 96 tile on 8 waves, direct-to-LDS ring): against numpy, with the thin-remainder peel of gemm.hip in play."""
     be = get_backend(backend)
     batch = 2
     dtype = np.complex128
@@ -64,39 +55,12 @@ def test_gemm_large_tile(backend, cfg, opA, opB, m, n, k, beta):
     C0 = crand((batch, m, n), dtype)
     al, bt = np.array([0.7 - 0.2j], dtype=dtype), np.array([beta * (-0.3 + 0.5j)], dtype=dtype)
     dA, dB, dC = be.dev(A), be.dev(B), be.dev(C0)
-    try:
-        assert be.lib.tuning(b"gemm_big", cfg) == 0
-        rc = be.lib.gemm(1, opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
-                         be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
-    finally:
-        be.lib.tuning(b"gemm_big", 0)
+    rc = be.lib.gemm(1, opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
+                     be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
     assert rc == 0
     f = {0: lambda x: x, 1: lambda x: x.transpose(0, 2, 1), 2: lambda x: x.conj().transpose(0, 2, 1)}
     ref = al[0] * (f[opA](A) @ f[opB](B)) + bt[0] * C0
     assert np.abs(be.host(dC) - ref).max() / np.abs(ref).max() < 1e-12
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-def test_gemm_register_staged_general_tile(backend):
-    """Knob gemm_dma: the fp64 general tile through the direct-to-LDS ring (1) and through the register-staged kernel (0, the default:
-    measured equally fast) give the same product."""
-    be = get_backend(backend)
-    m, n, k, batch = 70, 131, 45, 2
-    A, B = crand((batch, m, k), np.complex128), crand((batch, n, k), np.complex128)
-    one, zero = np.array([1.0 + 0j]), np.array([0j])
-    outs = []
-    dA, dB = be.dev(A), be.dev(B)
-    for knob in (0, 1):
-        dC = be.empty((batch, m, n), np.complex128)
-        try:
-            assert be.lib.tuning(b"gemm_dma", knob) == 0
-            rc = be.lib.gemm(1, 0, 2, m, n, k, one.ctypes.data, be.ptr(dA), k, m * k, be.ptr(dB), k, n * k, zero.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
-        finally:
-            be.lib.tuning(b"gemm_dma", 0)
-        assert rc == 0
-        outs.append(be.host(dC))
-    ref = A @ B.conj().transpose(0, 2, 1)
-    assert np.abs(outs[0] - ref).max() / np.abs(ref).max() < 1e-13 and np.abs(outs[1] - ref).max() / np.abs(ref).max() < 1e-13
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

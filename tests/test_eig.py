@@ -124,7 +124,7 @@ def _set_knobs(be, **kw):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(eig_vec=2, qr_chains=2)])
+@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(qr_chains=2, slab_spw=2)])
 def test_eig_tuning_knobs(backend, knobs):
     """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window, bulge chains per sweep; include/trx.h:
     trx_tuning) select different code paths, not results."""
@@ -142,22 +142,23 @@ def test_eig_tuning_knobs(backend, knobs):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("pipe", [2, 1])
-def test_eig_pipelined_slab_kernel(backend, pipe):
-    """The software-pipelined off-window update (fp64, n >= 128, dynamically claimed strips; full-width window frames with identity
-    padding, shifted up at the bottom of the matrix) against the one-strip-at-a-time kernel: same results.  slab_dyn = 2 forces the
-    dynamic path for this small batch; slab_pipe = 2 selects the pipelined kernel, 1 the default one."""
-    if backend == "emu" and pipe == 1:
-        pytest.skip("emulator time budget: the default kernel with dynamic strips runs in the other emulator tests")
+@pytest.mark.parametrize("spw", [4, 1])
+def test_eig_deferred_right_update(backend, spw):
+    """Sweeps of several window steps: the left update runs right behind each step (1 or 4 strips per wave), the right update of H and the
+    update of Z once per sweep over the whole link log (apply_links_kernel<1>: every row strip walks through all links whose window lies
+    below it).  A matrix that deflates in the middle (active blocks that end anywhere) and a dense one."""
+    if backend == "emu" and spw == 1:
+        pytest.skip("emulator time budget: one strip per wave is the default of the other emulator tests")
     be = get_backend(backend)
     n = 140 if backend == "emu" else 333
     A = (RNG.standard_normal((3, n, n)) + 1j * RNG.standard_normal((3, n, n))).astype(np.complex128)
     A[2] = 0.2 * A[2] + np.diag(np.linspace(-9, 9, n)).astype(np.complex128)
+    A[1][n // 2:, :n // 2] = 0                                     # block upper triangular: two independent active blocks
     try:
-        _set_knobs(be, slab_dyn=2, slab_pipe=pipe)
+        _set_knobs(be, slab_spw=spw)
         w, V, info = run_eig(be, A)
     finally:
-        _set_knobs(be, slab_dyn=0, slab_pipe=0)
+        _set_knobs(be, slab_spw=0)
     check(A, w, V, info, 1e-12)
 
 
@@ -218,52 +219,6 @@ def test_eig_balances_badly_scaled_input(backend):
         assert abs(abs(np.vdot(v, V[0][:, j])) - 1.0) < 1e-9, j
     assert np.allclose(np.linalg.norm(V[0], axis=0), 1.0, atol=1e-12)
     check(A[1:], w[1:], V[1:], info[1:], 1e-13)
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-def test_eig_vector_routes_agree(backend):
-    """The two eigenvector routes -- Schur vectors (QR with the unitary accumulated, triangular back-substitution) and inverse
-    iteration on the Hessenberg matrix behind an eigenvalues-only QR phase (knob eig_vec = 1 / 2) -- on matrices large enough for
-    sweeps of several window steps, interior deflations and a multi-wave inverse-iteration layout: same eigenvalues, both pass the
-    residual / conditioning checks, and the eigenvectors agree up to a phase."""
-    be = get_backend(backend)
-    n, batch = (136, 2) if backend == "emu" else (700, 2)
-    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
-    A[1] = 0.3 * A[1] + np.diag(np.linspace(-15, 15, n)).astype(np.complex128)
-    res = {}
-    for vec in (1, 2):
-        try:
-            _set_knobs(be, eig_vec=vec)
-            res[vec] = run_eig(be, A)
-        finally:
-            _set_knobs(be, eig_vec=0)
-        check(A, *res[vec], 1e-12)
-    for b in range(batch):
-        w1, V1 = res[1][0][b], res[1][1][b]
-        w2, V2 = res[2][0][b], res[2][1][b]
-        for j in range(n):
-            i = int(np.argmin(np.abs(w2 - w1[j])))
-            assert abs(w2[i] - w1[j]) < 1e-10 * np.abs(w1).max()
-            assert abs(abs(np.vdot(V1[:, j], V2[:, i])) - 1.0) < 1e-7, (b, j)
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(invit_wpl=2), dict(invit_wpl=2, invit_cfg=3, invit_ring=2), dict(invit_cfg=2, invit_ring=1), dict(invit_wpl=4, invit_cfg=4), dict(invit_cfg=5), dict(invit_cfg=6, invit_wpl=2), dict(invit_cfg=6, invit_ring=3), dict(invit_cfg=6, invit_xcd=1)])
-def test_eig_inverse_iteration_layouts(backend, knobs):
-    """The inverse-iteration kernel lays the two vectors of an eigenvalue over 64 x WPL lanes x SL slots (WPL chosen by n, 1024- or
-    512-thread workgroups): forced multi-wave layouts and the alternative slot / thread counts at a size with several slots per lane --
-    cross-wave pivot publication, column staging by the whole workgroup, padding eigenvalue groups -- give the same result quality."""
-    be = get_backend(backend)
-    n, batch = (150, 1) if backend == "emu" else (600, 2)
-    if backend == "gpu" and knobs in (dict(invit_wpl=2), dict(invit_cfg=2, invit_ring=1)):
-        pytest.skip("gpu time budget: covered by the emulator run of the same case")
-    A = (RNG.standard_normal((batch, n, n)) + 1j * RNG.standard_normal((batch, n, n))).astype(np.complex128)
-    try:
-        _set_knobs(be, eig_vec=2, **knobs)
-        w, V, info = run_eig(be, A)
-    finally:
-        _set_knobs(be, eig_vec=0, **{k: 0 for k in knobs})
-    check(A, w, V, info, 1e-12)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

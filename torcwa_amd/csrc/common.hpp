@@ -31,21 +31,6 @@
 #define TRX_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // the same with any constant expression 0 .. 63 (gfx9 encodes a 6-bit vmcnt)
 #define TRX_WAIT_VMCNT_IMM(expr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(expr) : "memory")
-// fp64 MFMA accumulators PINNED to fixed AGPRs: accumulator number IDX (a compile-time constant) is a[8 IDX : 8 IDX + 7].
-// Why not the builtin: hipcc selects ONE form of the MFMA per kernel -- accumulators in VGPRs when the kernel fits 256 registers, in AGPRs
-// otherwise -- and in the AGPR form its register allocator keeps loop-carried accumulators in VGPRs and copies them through
-// v_accvgpr_write / v_accvgpr_read around every MFMA (8 + 8 moves per MFMA in the ISA of the large-tile GEMM, also with an "+a" asm
-// operand: the loop phi stays a VGPR value).  Here the accumulators are not C++ values at all: the instruction text names the registers,
-// every such statement declares all AGPRs clobbered (so the compiler keeps nothing of its own there across the loop; the kernel's ISA must
-// contain no v_accvgpr_* besides these -- checked by tests/test_host_logic.py), they are zeroed and read back by TRX_ACC_ZERO / TRX_ACC_READ.
-// The compiler does not know these are MFMAs: the kernel keeps two MFMAs on one accumulator >= 24 MFMAs apart and calls TRX_ACC_DRAIN
-// (the write-back of the last MFMA) before the first TRX_ACC_READ.
-#define TRX_ACC_DECL(count)
-#define TRX_ACC_MFMA(IDX, a, b) ::trx::accreg::mfma<IDX>(a, b)
-#define TRX_ACC_ZERO(IDX) ::trx::accreg::zero<IDX>()
-#define TRX_ACC_READ(IDX, R, out) ((out) = ::trx::accreg::read<IDX, R>())        // element R (0 .. 3) of accumulator IDX
-#define TRX_ACC_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
-#define TRX_ACC_REGS_HPP 1
 #endif
 // the same with a compile-time constant expression (0 .. 15)
 #define TRX_WAIT_VMCNT_N(expr)                                                                     \
@@ -64,10 +49,6 @@
 
 #define TRX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel), grid, block, shmem, stream, __VA_ARGS__)
-
-#ifdef TRX_ACC_REGS_HPP
-#include "acc_regs.hpp"
-#endif
 
 namespace trx {
 
@@ -206,11 +187,11 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);
 int lu_set_knob(const char* key, int value);          // trx_tuning("lu_split", rows)
-// large-tile fp64 kernel (gemm_big.hip): tile configuration cfg = 1 .. 3
-void gemm_big_tile(int cfg, int* bm, int* bn);
-int gemm_big(hipStream_t s, int cfg, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
+// large-tile fp64 kernel (gemm_big.hip)
+void gemm_big_tile(int* bm, int* bn);
+int gemm_big(hipStream_t s, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
              int ldb, long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper);
-int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_dma", 0 / 1)
+int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_big", 0 / 4)
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);

@@ -14,9 +14,9 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static int eig_vec_env() {
     const char* e = getenv("TRX_EIG_VEC");
     const int v = e ? atoi(e) : 0;
-    return (v >= 0 && v <= 3) ? v : 0;
+    return (v == 0 || v == 1 || v == 3) ? v : 0;
 }
-static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic (= Schur vectors), 1 Schur vectors, 2 inverse iteration
+static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automatic, 1 all-fp64 (all-fp32 for complex64 input) Schur vectors, 3 mixed wherever n >= 8
 // Per-call options (trx_eig_opts / trx_eig_ws_bytes_opts): route and Newton steps of THIS call, held thread-locally for the duration of the
 // call on the calling host thread -- the process-global knobs are only the defaults, so two threads (or a complex64 and a complex128 solver
 // in one process) can no longer overwrite each other's setting between trx_tuning and trx_eig.  -1 = not set (use the knob).
@@ -27,13 +27,12 @@ struct EigCallOpts {
     EigCallOpts(unsigned opts) { const int r = opts & 0xF, v = (opts >> 4) & 0xF; tl_refine = r ? r : -1; tl_eig_vec = v ? v : -1; }
     ~EigCallOpts() { tl_refine = -1; tl_eig_vec = -1; }
 };
-bool eig_uses_invit(int n) { return cur_eig_vec() == 2 && n <= INVIT_NMAX && n >= 2; }
 // mixed-precision route (fp32 eigendecomposition + Newton refinement in fp64, eig_refine.hip): fp64 problems of at least 256 rows
 // Automatic: batches of at least 8 (measured, n = 1922: +6 % of the whole layer-solve step at batch 16, 64 and 128; a single n = 5202
 // matrix, whose fp64 solve is a latency chain that fp32 does not shorten, loses 60 % to the extra refinement work).
 bool eig_uses_mixed(int n, int batch, size_t elem) { return elem == 8 && ((cur_eig_vec() == 3 && n >= 8) || (cur_eig_vec() == 0 && n >= 256 && batch >= 8)); }
 int eig_set_knob(const char* key, int value) {
-    if (std::string(key) != "eig_vec" || value < 0 || value > 3) return TRX_ERR_ARG;
+    if (std::string(key) != "eig_vec" || (value != 0 && value != 1 && value != 3)) return TRX_ERR_ARG;
     g_eig_vec = value;
     return TRX_OK;
 }
@@ -64,15 +63,17 @@ size_t eig_ws_bytes_t(int n, int batch) {
     const size_t e = sizeof(cx<T>), B = batch, N = n;
     size_t tot = 0;
     tot += al256(e * B * N * N) * 2;                                  // Z, X
-    if (eig_uses_invit(n)) tot += al256(e * B * N * N) + al256(B * N * N);     // Ht, SW: only the inverse-iteration route (knob eig_vec) needs them
-    tot += al256(sizeof(T) * B);                                      // hnorm
     tot += al256(e * B * N * EigPlan::HNB) * 2;                       // Vp, Yp
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Tp
     tot += al256(e * B * EigPlan::HNB * N) * 2;                       // W1, W2
     tot += al256(e * B * N * 2 * EigPlan::HNB) * 2;                   // YV, BC
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Sm
     tot += al256(e * B * EigPlan::HNB) * 2;                           // tau, tvec
-    tot += al256(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);   // U
+    tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U (dense link)
+    {   // link log of a sweep: window unitaries + link records
+        const size_t slots = (size_t)qr_log_slots(n) * qr_chains_for(batch);
+        tot += al256(e * B * slots * EigPlan::QW * EigPlan::QW) + al256(sizeof(QrLink) * B * slots);
+    }
     tot += al256(e * B * EigPlan::QKC * EigPlan::QNS);                // shifts
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
@@ -98,9 +99,6 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
         Bf.mixed_pool = (char*)Bf.Z;
         Bf.mixed_pool_bytes = pool > zx ? pool : zx;
     }
-    Bf.Ht = nullptr; Bf.SW = nullptr;
-    if (eig_uses_invit(n)) { Bf.Ht = (cx<T>*)take(e * B * N * N); Bf.SW = (unsigned char*)take(B * N * N); }
-    Bf.hnorm = (T*)take(sizeof(T) * B);
     Bf.Vp = (cx<T>*)take(e * B * N * EigPlan::HNB);
     Bf.Yp = (cx<T>*)take(e * B * N * EigPlan::HNB);
     Bf.Tp = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
@@ -111,7 +109,12 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.Sm = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.tvec = (cx<T>*)take(e * B * EigPlan::HNB);
-    Bf.U = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QW * EigPlan::QW);
+    Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
+    {
+        const size_t slots = (size_t)qr_log_slots(n) * qr_chains_for(batch);
+        Bf.Ulog = (cx<T>*)take(e * B * slots * EigPlan::QW * EigPlan::QW);
+        Bf.links = (QrLink*)take(sizeof(QrLink) * B * slots);
+    }
     Bf.shifts = (cx<T>*)take(e * B * EigPlan::QKC * EigPlan::QNS);
     Bf.bal_d = (T*)take(sizeof(T) * B * N);
     Bf.bal_w = (T*)take(sizeof(T) * 3 * B * N);
@@ -199,19 +202,10 @@ int eig_after_balance(hipStream_t s, const EigBuffers<T>& B, void* w, void* V, i
     int rc = hessenberg<T>(s, B, n, batch);
     if (rc) return rc;
     TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
-    // Eigenvector route (knob eig_vec: 0 = automatic, 1 = Schur vectors, 2 = inverse iteration).  Inverse iteration (eig_invit.hip): the
-    // QR phase runs for eigenvalues only -- a third of the off-window work and no Z -- and each eigenvector costs one O(n^2) solve.
-    // Automatic = Schur vectors: measured on MI355X (round 3, profiles/r03_invit_route.txt) the eigenvalues-only QR phase is 0.5 s shorter
-    // per 128-matrix batch at n = 1922, but the solve kernel (a latency-bound recurrence of n barrier-separated steps per eigenvalue
-    // group, 7 TF-equivalent of fp64 vector work) takes 1.05 s, and the route loses at every batch size from 1 to 128.
-    const bool invit = eig_uses_invit(n);
-    if (invit) {
-        rc = invit_prepare<T>(s, B, n, batch);
-        if (rc) return rc;
-    }
-    rc = hessenberg_qr<T>(s, B, n, batch, info, invit ? 0 : 1);
+    // Schur vectors: T = Z^H H Z with Z accumulated, eigenvectors of T by blocked back-substitution, back-transform.  (An eigenvalues-only
+    // QR phase + inverse iteration on H was built in round 3, lost at every batch size -- profiles/r03_invit_route.txt -- and was removed.)
+    rc = hessenberg_qr<T>(s, B, n, batch, info);
     if (rc) return rc;
-    if (invit) return invit_vectors<T>(s, B, n, batch, (cx<T>*)w, (cx<T>*)V);
     return schur_vectors<T>(s, B, n, batch, (cx<T>*)w, (cx<T>*)V);
 }
 }  // namespace
@@ -300,7 +294,7 @@ extern "C" int trx_tuning(const char* key, int value) {
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::refine_set_knob(key, value);
-    return rc == TRX_OK ? rc : trx::invit_set_knob(key, value);
+    return rc;
 }
 
 extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {

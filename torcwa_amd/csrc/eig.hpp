@@ -24,20 +24,24 @@ struct QrState {
     int tau_last[EigPlan::QKC];
     int mode;                     // see QR_* below
     int stall, sweeps;
-    int w0[EigPlan::QKC], w1[EigPlan::QKC];   // window of each chain's last step: its pending off-window update acts on [w0, w1)
+    int w0[EigPlan::QKC], w1[EigPlan::QKC];   // [0]: window of the pending dense link (AED window / finished block), set by the prepare kernel
     int fail;                     // number of unconverged eigenvalues on failure
-    int strip_next;               // next unclaimed strip of the pending off-window update (dynamic strip scheduling; reset per window step)
 };
 enum { QR_CHASE = 0, QR_SMALL_PENDING = 1, QR_SMALL_APPLIED = 2, QR_IDLE = 3, QR_DONE = 4, QR_AED_CHASE = 5 };
+// One entry of a sweep's link log (slot = window step, per chain): the window [w0, w1) whose unitary the update kernels apply.
+//   QRL_CHASE: unitary of a window step (U log, same slot): left update from column e on right behind the step, right / Z update deferred
+//   QRL_DENSE: unitary of an AED window / a finished small block (per-matrix buffer U): all sides at once
+struct QrLink { int w0, w1, kind, e; };
+enum { QRL_NONE = 0, QRL_CHASE = 1, QRL_DENSE = 2 };
+// chains per sweep of a batch and slots of the link log for order n (eig_qr.hip; the workspace layout depends on both)
+int qr_chains_for(int batch);
+int qr_log_slots(int n);
 
 template <class T>
 struct EigBuffers {
     cx<T>* A;      // [B,n,n] input, becomes H then T
     cx<T>* Z;      // [B,n,n] accumulated unitary
-    cx<T>* X;      // [B,n,n] triangular eigenvectors (Schur route) / eigenvectors of H (inverse iteration)
-    cx<T>* Ht;     // [B,n,n] transposed copy of the Hessenberg matrix (inverse iteration streams its columns)
-    unsigned char* SW;   // [B,n,n] interchange flags of the inverse-iteration eliminations
-    T* hnorm;      // [B] infinity norm of the Hessenberg matrix
+    cx<T>* X;      // [B,n,n] triangular eigenvectors
     cx<T>* Vp;     // [B,n,HNB] panel reflectors (dense, explicit zeros/ones)
     cx<T>* Yp;     // [B,n,HNB]
     cx<T>* Tp;     // [B,HNB,HNB]
@@ -48,7 +52,9 @@ struct EigBuffers {
     cx<T>* Sm;     // [B,HNB,HNB]   V^H Y
     cx<T>* tau;    // [B,HNB]
     cx<T>* tvec;   // [B,HNB]  V^H v of the current panel column
-    cx<T>* U;      // [B,QKC,QW,QW] window unitary of each chain
+    cx<T>* U;      // [B,QW,QW] unitary of the last AED window / finished small block (dense link)
+    cx<T>* Ulog;   // [B,slots,chains,QW,QW] window unitaries of the running sweep (link log)
+    QrLink* links; // [B,slots,chains]
     cx<T>* shifts; // [B,QKC,QNS]
     T* bal_d;      // [B,n] balancing scale D (A_balanced = D^-1 A D)
     T* bal_w;      // [2,B,n] balancing scratch: row norms, column norms (sized for 3)
@@ -90,18 +96,12 @@ template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, in
 
 template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
-// wantz = 1: Schur form (T in A, unitary accumulated into Z);  wantz = 0: eigenvalues only (diagonal of A on return; the off-window
-// updates are restricted to the active diagonal block, A is NOT a Schur form afterwards and Z is not touched)
-template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info, int wantz);
+// Schur form: T in A, unitary accumulated into Z
+template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
 int qr_set_knob(const char* key, int value);
 int eig_set_knob(const char* key, int value);
-int invit_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 // V <- D V (undo of the balancing) with unit 2-norm columns
 template <class T> int finish_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* V);
-// eigenvectors by inverse iteration on the Hessenberg matrix (eig_invit.hip): invit_prepare before the QR phase, invit_vectors after it
-template <class T> int invit_prepare(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
-template <class T> int invit_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
-constexpr int INVIT_NMAX = 8192;      // largest n the inverse-iteration kernel is laid out for
 
 }  // namespace trx

@@ -4,25 +4,29 @@
 // Design for MI355X.  The sequential part of the QR algorithm (generating rotations) only ever touches a narrow
 // diagonal window, so it runs as ONE workgroup per matrix entirely out of LDS (qr_window_kernel: a chain of up to
 // QNS single-shift bulges, 2 rows apart, is chased through a QW x QW window while the window's unitary U is
-// accumulated in LDS).  Everything off the window is updated afterwards with U by wide, embarrassingly parallel
-// slab kernels (apply_left / apply_right) that stream H and Z through LDS once per window step.  Per-matrix
-// progress (active block, shifts, chase position) lives in device memory, so one fixed launch schedule serves the
-// whole batch; matrices that have nothing to do in a step see an empty window and exit.
+// accumulated in LDS).  Everything off the window is updated with U by wide, embarrassingly parallel kernels on the
+// matrix cores (apply_links_kernel).  Per-matrix progress (active block, shifts, chase position) lives in device memory,
+// so one fixed launch schedule serves the whole batch; matrices that have nothing to do in a step see an empty window and exit.
 //
 //   qr_prepare_kernel  (1 wave / matrix)  deflation scan, active-block bookkeeping, aggressive early deflation on the
 //                                         trailing window (in-LDS single-shift QR), shifts for up to QKC chains; blocks
 //                                         <= QNMIN are finished here by the same in-LDS QR with U accumulated.
-//   qr_window_kernel   (1 workgroup per matrix AND chain) one window step of each bulge chain.
-//   apply_window_kernel<PART 0>  H[w0:w1, w1:n] <- U^H H[w0:w1, w1:n]                                   (left updates, all chains)
-//   apply_window_kernel<PART 1>  H[0:w0, w0:w1] <- H[0:w0, w0:w1] U ;  Z[:, w0:w1] <- Z[:, w0:w1] U     (right updates, all chains)
+//   qr_window_kernel   (1 workgroup per matrix AND chain) one window step of each bulge chain; the window unitary and
+//                                         its position go into the LINK LOG of the sweep (slot = window step).
+//   apply_links_kernel<0>   per window step:  H[w0:w1, w1:n) <- U^H H[w0:w1, w1:n)   -- the left update, the only part the NEXT
+//                                         window step depends on (its new columns);
+//   apply_links_kernel<1>   ONCE per sweep:   H[0:w0, w0:w1) <- H[0:w0, w0:w1) U,  Z[:, w0:w1) <- Z[:, w0:w1) U  for every link of the
+//                                         log, in order.  No window step of the same sweep reads what these touch (rows ABOVE a window),
+//                                         left and right multiplications commute, so two thirds of the off-window work leave the
+//                                         window -> update -> window chain and run as one large launch per sweep, each row strip walking
+//                                         through the links with its 16 x 64 block hot in L2.
 //
 // Several bulge chains per sweep.  A sweep sends up to QKC chains of QNS shifts each down the active block, chain c following
 // chain c-1 at a distance of at least one window (a chain moves only if its new window ends above the last bulge of the chain
 // ahead), so that one window step advances all of them: their windows are disjoint diagonal blocks (independent workgroups), the
 // left updates of different chains touch disjoint rows and the right updates disjoint columns.  A block that two chains both
-// reach (rows of the upper window x columns of the lower one) gets U_a^H from the left in PART 0 and U_b from the right in PART 1
-// -- the two commute, and the two launches order them.  Up to 48 of the AED window's eigenvalues are thus used per sweep
-// instead of 16: a third of the AED calls and of the latency-bound window steps for the same number of shifts.
+// reach (rows of the upper window x columns of the lower one) gets U_a^H from the left and U_b from the right -- the two commute.
+// Up to 48 of the AED window's eigenvalues are thus used per sweep instead of 16 (default for one or two matrices).
 #include "eig.hpp"
 #include <cstdlib>
 #include <limits>
@@ -96,31 +100,23 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     return R;
 }
 
-// Synchronisation of the single-wave in-LDS routines below.  In a 64-thread workgroup they use the block barrier; when the same code
-// runs on wave 0 of a larger workgroup (multi-wave AED kernel) a block barrier would wait for the other waves, and none is needed: one
-// wave's LDS operations execute in program order, so only the compiler has to be kept from reordering them (wave_sync).
-struct BlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
-struct WaveSync { __device__ __forceinline__ void operator()() const { wave_sync(); } };
-
 // Schur form of an m x m (m <= SM = 64) upper Hessenberg matrix held in LDS, by EXPLICITLY shifted QR iterations executed
 // by ONE wave.  Lane c owns column c while Q^H is applied from the left (the rotation that zeroes H[r+1,r] is generated by
 // lane r as soon as its column has received the previous rotations, and broadcast through LDS), and row c while Q is
 // applied from the right (all rotations are known by then, so the lanes run independently).  Compared with a rotation-by-
 // rotation implicit chase this keeps every lane busy and needs no block barrier inside a QR iteration.
 // On return Hs is upper triangular; if Us != nullptr it holds U with H_in = U T U^H.  Returns false if not converged.
-// ihi0 / lstop: work on the leading (ihi0 + 1) x (ihi0 + 1) part only and stop as soon as everything below row lstop has deflated
-// (defaults: the whole matrix); *ihi_out receives the index the loop stopped at.
 // BC: the inputs (f, g) of rotation r are broadcast from lane r with v_readlane and EVERY lane generates the rotation, instead of lane r
 // generating it and five ds_bpermute shuffles distributing the result (one LDS round trip less on the chain of every rotation).
-template <class T, class SY = BlockSync, bool BC = false>
-__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr, int ihi0 = -1, int lstop = 0, int* ihi_out = nullptr) {
-    const SY sync;
+template <class T, bool BC = false>
+__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr) {
+    const auto sync = [] { __syncthreads(); };
     const int lane = threadIdx.x;
     long long t_left = 0, t_right = 0, t_u = 0, t_pre = 0, tt = 0, n_it = 0, n_rot = 0;
     if (dbg) tt = clock64();
     const T ulp = eps_of<T>::value;
-    int ihi = ihi0 >= 0 ? ihi0 : m - 1, its = 0, total = 0;
-    while (ihi > lstop) {
+    int ihi = m - 1, its = 0, total = 0;
+    while (ihi > 0) {
         // deflation: flush negligible subdiagonals of [1, ihi] to zero, find the active block [l, ihi]
         int small = 0;
         if (lane >= 1 && lane <= ihi) {
@@ -135,7 +131,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         sync();
         if (l == ihi) { --ihi; its = 0; continue; }
         ++its; ++total;
-        if (total > 40 * m) { if (ihi_out) *ihi_out = ihi; return false; }
+        if (total > 40 * m) return false;
         cx<T> sig;
         {
             const cx<T> a = Hs[(ihi - 1) * SLD + ihi - 1], bq = Hs[(ihi - 1) * SLD + ihi], cq = Hs[ihi * SLD + ihi - 1], d = Hs[ihi * SLD + ihi];
@@ -221,15 +217,14 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         sync();
     }
     if (dbg && lane == 0) { dbg[0] += t_pre; dbg[1] += t_left; dbg[2] += t_right; dbg[3] += t_u; dbg[4] += n_it; dbg[5] += n_rot; }
-    if (ihi_out) *ihi_out = ihi;
     return true;
 }
 
 // Swap the adjacent diagonal entries k, k+1 of the upper-triangular Ts (order m <= 64) by one rotation, accumulating into
 // Vs (LAPACK ztrexc for complex Schur forms).  One wave.
-template <class T, class SY = BlockSync>
+template <class T>
 __device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k, const int SLD) {
-    const SY sync;
+    const auto sync = [] { __syncthreads(); };
     const int lane = threadIdx.x;
     const cx<T> a = Ts[k * SLD + k], bq = Ts[(k + 1) * SLD + k + 1], x = Ts[k * SLD + k + 1];
     const Rot<T> R = rotg_fast(x, bq - a);
@@ -256,9 +251,9 @@ __device__ void schur_swap(cx<T>* Ts, cx<T>* Vs, int m, int k, const int SLD) {
 
 // Householder reflector for x[0:len] held in LDS at stride `inc` (LAPACK zlarfg): H = I - tau v v^H, H^H x = beta e1.
 // All lanes compute redundantly; v (v[0] = 1) is written to vw[0:len] by the lanes; returns tau, beta.  len <= 64.
-template <class T, class SY = BlockSync>
+template <class T>
 __device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& tau, T& beta) {
-    const SY sync;
+    const auto sync = [] { __syncthreads(); };
     const int lane = threadIdx.x;
     const cx<T> alpha = x[0];
     T xn2 = (lane >= 1 && lane < len) ? norm2(x[lane * inc]) : T(0);
@@ -279,9 +274,9 @@ __device__ void small_larfg(const cx<T>* x, int inc, int len, cx<T>* vw, cx<T>& 
 
 // Apply H = I - tau v v^H (v on rows/cols [o, o+len)) to the m x m Ts from both sides (Ts <- H^H Ts H, left side on
 // columns >= c0, right side on rows < nrows_t) and to Vs from the right (all m rows).  One wave, m <= 64.
-template <class T, class SY = BlockSync>
+template <class T>
 __device__ void small_apply_reflector(cx<T>* Ts, cx<T>* Vs, int m, int nrows_t, int o, int len, int c0, const cx<T>* vw, cx<T> tau, const int SLD) {
-    const SY sync;
+    const auto sync = [] { __syncthreads(); };
     const int lane = threadIdx.x;
     if (lane >= c0 && lane < m) {                                   // left: lane = column
         cx<T> w(T(0), T(0));
@@ -309,7 +304,7 @@ template <class T>
 __global__ __launch_bounds__(64) void qr_init_kernel(QrState* __restrict__ st, int n) {
     if (threadIdx.x == 0) {
         QrState s;
-        s.ilo = 0; s.ihi = n - 1; s.nch = 0; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0; s.fail = 0; s.strip_next = 0;
+        s.ilo = 0; s.ihi = n - 1; s.nch = 0; s.mode = QR_IDLE; s.stall = 0; s.sweeps = 0; s.fail = 0;
         for (int c = 0; c < QKC; ++c) { s.k[c] = 0; s.tau[c][0] = s.tau[c][1] = 1; s.tau_last[c] = 0; s.w0[c] = 0; s.w1[c] = 0; }
         st[blockIdx.x] = s;
     }
@@ -347,7 +342,7 @@ template <class T, bool BC>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        int sm, int wantz, long long* dbg_all = nullptr) {
+                                                        int sm, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
@@ -427,9 +422,9 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
         }
         __syncthreads();
-        const bool ok = small_schur<T, BlockSync, BC>(Hs, m, Us, rots, SLD);
+        const bool ok = small_schur<T, BC>(Hs, m, Us, rots, SLD);
         __syncthreads();
-        cx<T>* U = Uall + (long)b * QKC * QW * QW;            // chain slot 0 carries the unitary of a finished block / AED window
+        cx<T>* U = Uall + (long)b * QW * QW;                  // the unitary of a finished block / AED window (a DENSE link of the next sweep)
         for (int e = lane; e < m * m; e += 64) {
             const int r = e / m, c = e - r * m;
             H[(long)(ilo + r) * n + ilo + c] = (r <= c) ? Hs[r * SLD + c] : cx<T>(T(0), T(0));
@@ -437,7 +432,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
         }
         if (lane == 0) {
             clear_windows(st);
-            if (wantz) { st.w0[0] = ilo; st.w1[0] = ihi + 1; }        // eigenvalues only: nothing outside the finished block needs its unitary
+            st.w0[0] = ilo; st.w1[0] = ihi + 1;
             st.mode = QR_SMALL_PENDING; st.ihi = ilo - 1; st.ilo = 0; st.stall = 0;
             if (!ok) st.fail += m;
             stall_[b] = st;
@@ -462,7 +457,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[6] += t1 - tk0; tk0 = t1; }       // scans + window load
-    const bool okw = small_schur<T, BlockSync, BC>(Hs, nw, Us, rots, SLD, dbg);
+    const bool okw = small_schur<T, BC>(Hs, nw, Us, rots, SLD, dbg);
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[7] += t1 - tk0; tk0 = t1; }       // Schur total
     int ns = nw;
@@ -549,7 +544,7 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[9] += t1 - tk0; tk0 = t1; }       // Hessenberg restore
     {
-        cx<T>* U = Uall + (long)b * QKC * QW * QW;
+        cx<T>* U = Uall + (long)b * QW * QW;
         for (int e = lane; e < nw * nw; e += 64) {
             const int r = e / nw, c = e - r * nw;
             cx<T> v = Hs[r * SLD + c];
@@ -610,7 +605,8 @@ template <class T> struct RotCS { T c; cx<T> s; };
 // 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Uall, const cx<T>* __restrict__ shifts_all, int par, long long* dbg_all = nullptr) {
+                                                        cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
+                                                        int par, int nslot, int kc, int q, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
@@ -619,13 +615,22 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
     QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
-    if (t == 0) { sst = st_all[b]; if (ch == 0) st_all[b].strip_next = 0; }
+    if (t == 0) sst = st_all[b];
     __syncthreads();
+    // this step's entry of the link log: EVERY exit path writes it (the update kernels walk over all slots of the sweep)
+    QrLink* link = links_all + ((long)b * nslot + q) * kc + ch;
     const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
     // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
     // positions go to the [par] copy, which nobody writes in this step.
-    if (st.mode == QR_SMALL_PENDING) { if (t == 0 && ch == 0) st_all[b].mode = QR_SMALL_APPLIED; return; }      // this slot applies the block's unitary
-    if (st.mode == QR_AED_CHASE) { if (t == 0 && ch == 0) st_all[b].mode = QR_CHASE; return; }                  // this slot applies the AED unitary
+    if (st.mode == QR_SMALL_PENDING || st.mode == QR_AED_CHASE) {
+        // this slot applies the unitary of the finished block / the AED window (written by the prepare kernel): a dense link, updated on all sides at once
+        if (t == 0) {
+            QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
+            if (ch == 0) { l.w0 = st.w0[0]; l.w1 = st.w1[0]; l.kind = QRL_DENSE; l.e = l.w1; st_all[b].mode = st.mode == QR_SMALL_PENDING ? QR_SMALL_APPLIED : QR_CHASE; }
+            *link = l;
+        }
+        return;
+    }
     const int tau0 = st.tau[ch][par];
     bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
     const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
@@ -643,7 +648,8 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     }
     if (!move) {
         if (t == 0) {
-            if (st.w0[ch] != 0 || st.w1[ch] != 0) { st_all[b].w0[ch] = 0; st_all[b].w1[ch] = 0; }
+            QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
+            *link = l;
             st_all[b].tau[ch][par ^ 1] = tau0;
         }
         return;
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
     }
     if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
-    cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
+    cx<T>* U = Ulog_all + (((long)b * nslot + q) * kc + ch) * QW * QW;
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
     {
         // phase 1 done: the window goes back to H, the buffer becomes U = I
@@ -783,23 +789,24 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
     }
     if (t == 0) {
-        st_all[b].tau[ch][par ^ 1] = tau_end + 1; st_all[b].w0[ch] = w0; st_all[b].w1[ch] = w1;
+        st_all[b].tau[ch][par ^ 1] = tau_end + 1;
+        QrLink l; l.w0 = w0; l.w1 = w1; l.kind = QRL_CHASE; l.e = w1;
+        *link = l;
     }
     if (dbg) dbg[14] += clock64() - tk0;
 }
 
 // Off-window updates on the matrix cores: H[w0:w1, w1:n) <- U^H H[w0:w1, w1:n)   (left),  H[0:w0, w0:w1) <- H[0:w0, w0:w1) U  and
-// Z[:, w0:w1) <- Z[:, w0:w1) U   (right), with the window unitary U (ww x ww, ww <= 64) of the last window step.
+// Z[:, w0:w1) <- Z[:, w0:w1) U   (right), with the window unitary U (ww x ww, ww <= 64) of a link of the log.
 //
 // Streaming design: the work of one matrix is cut into STRIPS of 16 columns (left) or 16 rows (right); one wave owns a strip,
-// i.e. a 64 x 16 / 16 x 64 output block = four 16x16 MFMA tiles with the full K = ww.  U is staged ONCE per workgroup into LDS
+// i.e. a 64 x 16 / 16 x 64 output block = four 16x16 MFMA tiles with the full K = ww.  U is staged ONCE per workgroup and link into LDS
 // (split re/im planes) and serves as the A operand of the left update (U^H: the conjugation is folded into the signs of the
 // four real MFMAs) and as the B operand of the right update; the streamed operand goes global memory -> registers directly
-// in MFMA fragment layout (no LDS staging, no barrier after the prologue), and the next strip of the wave is prefetched into
-// registers while the current one is multiplied.  The k index of an MFMA step is permuted (k = 16c + 4*(lane>>4) + j, kstep()) so that
+// in MFMA fragment layout (no LDS staging).  The k index of an MFMA step is permuted (k = 16c + 4*(lane>>4) + j, kstep()) so that
 // a lane of the right update reads 4 consecutive elements of its row; both operands use the same permutation.
-// Algorithmic intensity: 8*16*64*64 flops per 2*16 KiB moved = 16 flop/B, i.e. the update sits at the MFMA/HBM balance point
-// (78.6 TF / 16 = 4.9 TB/s): every byte is touched exactly once per window step.
+// Algorithmic intensity: 8*16*64*64 flops per 2*16 KiB moved = 16 flop/B in fp64 (32 in fp32); the deferred right update re-reads, per link,
+// a block whose left 33 columns it wrote itself one link earlier (L2-hot), so about half of that traffic reaches HBM.
 constexpr int MLD = 72;           // LDS plane row stride: element U[k][c] at [k*MLD + c]
 // k index a lane of k-group lk (= lane >> 4) supplies at MFMA step (h, cc, j): k = kstep(h, cc, j) + KLS * lk.  Permuted order
 // (16 c + 4 lk + j): the four loads (j) of a lane of the right update are 64 contiguous bytes.  The natural order 4 step + lk
@@ -814,61 +821,16 @@ struct SlabStrip {       // wave-uniform description of one strip
     int a0, lim;         // first column / row of the strip, end of the valid column / row range
 };
 
-// Regions of the off-window update of one window step.  wantz (Schur form): left update on all columns right of the window, right update
-// on all rows above it, and the window's columns of Z.  Eigenvalues only: the left update stops at the end of the active block, the right
-// update starts at its first row, Z is not touched -- everything outside the active diagonal block is irrelevant to the eigenvalues.
-struct SlabRanges {
-    int nL, nR, nZ;      // strips (16 columns / rows) of the left update, the right update of H, the update of Z
-    int lc0, lclim;      // left update: first column, end of the column range
-    int rr0;             // right update of H: first row (the range ends at w0)
-};
-__device__ __forceinline__ SlabRanges slab_ranges(const QrState& st, int n, int w0, int w1, int wantz) {
-    SlabRanges r;
-    r.lc0 = w1;
-    if (wantz) { r.lclim = n; r.rr0 = 0; r.nZ = (n + 15) >> 4; }
-    else { r.lclim = st.ihi + 1 < n ? st.ihi + 1 : n; r.rr0 = st.ilo < w0 ? st.ilo : w0; r.nZ = 0; }
-    r.nL = r.lclim > w1 ? (r.lclim - w1 + 15) >> 4 : 0;
-    r.nR = (w0 - r.rr0 + 15) >> 4;
-    return r;
-}
-
-// strip g of PART 0 (left update: nL strips of 16 columns of H right of the window), PART 1 (right updates: nR strips of 16
-// rows of H above the window, then the strips of Z) or PART 2 (everything: left | right-H | Z)
-template <class T, int PART>
-__device__ __forceinline__ SlabStrip<T> slab_locate(int g, const SlabRanges& R, cx<T>* H, cx<T>* Z, int n, int w0) {
-    SlabStrip<T> d;
-    if (PART == 2) { if (g < R.nL) { d.X = H; d.side = 0; d.a0 = R.lc0 + 16 * g; d.lim = R.lclim; return d; } g -= R.nL; }
-    if (PART == 0) { d.X = H; d.side = 0; d.a0 = R.lc0 + 16 * g; d.lim = R.lclim; }
-    else if (g < R.nR) { d.X = H; d.side = 1; d.a0 = R.rr0 + 16 * g; d.lim = w0; }
-    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - R.nR); d.lim = n; }
-    return d;
-}
-
 // registers x[4cc + j] <- streamed operand element k = kstep(h, cc, j) + lk (half h of the strip's K range) of this lane's
 // column (left) / row (right).  Out-of-range coordinates are CLAMPED to a valid element of the same matrix and the value is
 // used as is: for k >= ww it meets a zero row of the padded U in LDS, and a lane whose row / column lies outside the region
 // only feeds output elements that are never stored.  (No select after the load: the loaded registers have no consumer until
 // the MFMAs of the next strip, so the loads stay in flight behind the current strip's arithmetic.)
-// FULL (the window has all QW rows / columns: no clamp on k): the address is split into ONE lane-dependent 32-bit offset per strip
-// and a wave-uniform part per load that goes into the scalar base, so that 16 loads cost one address register instead of 16.
-template <class T, bool FULL = false>
+template <class T>
 __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int n, int w0, int ww, int lane, cx<T> (&x)[8]) {
     const int lr = lane & 15, lk = lane >> 4;
     const int a = d.a0 + lr;
     const int ac = a < d.lim ? a : d.lim - 1;
-    if constexpr (FULL) {
-        const unsigned ksu = (d.side == 0 ? (unsigned)n : 1u) * (unsigned)sizeof(cx<T>);                 // wave-uniform
-        const unsigned lane_off = (d.side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>) + (unsigned)(KLS * lk) * ksu;
-        const char* base = reinterpret_cast<const char*>(d.X);
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const char* pb = base + (size_t)kstep(h, cc, j) * ksu;                                        // scalar
-                x[4 * cc + j] = *reinterpret_cast<const cx<T>*>(pb + lane_off);
-            }
-        return;
-    }
     // 32-bit BYTE offsets from the wave-uniform matrix base (scalar base + 32-bit vector offset addressing; one address
     // register per access instead of two): requires n*n*sizeof(cx<T>) < 4 GiB, i.e. n < 16384 for complex128 (checked on the host)
     const unsigned p0 = (d.side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>);
@@ -883,7 +845,9 @@ __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int
         }
 }
 
-template <class T, int SIDE>
+// BAND (see slab_multiply_half_3m): output tile q skips the k chunks c >= q + 2 of a chase unitary (compile-time conditions: h, cc, q are
+// unrolled constants)
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int lane, const cx<T> (&x)[8],
                                                    typename Mfma<T>::acc_t (&accR)[4], typename Mfma<T>::acc_t (&accI)[4]) {
     const int lr = lane & 15, lk = lane >> 4;
@@ -891,31 +855,35 @@ __device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, con
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int chunk = 2 * h + cc;
             const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
             T ur[4], ui[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q]; }
+            for (int q = 0; q < 4; ++q) {
+                if (BAND && chunk >= q + 2) continue;
+                ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
+            }
             if (SIDE == 1) {          // C = X U:      Cr += xr ur - xi ui,  Ci += xr ui + xi ur          (A = x, B = u)
                 const T nxi = -xi;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accR[q] = Mfma<T>::mma(xr, ur[q], accR[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(xr, ur[q], accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accI[q] = Mfma<T>::mma(xr, ui[q], accI[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xr, ui[q], accI[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accR[q] = Mfma<T>::mma(nxi, ui[q], accR[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(nxi, ui[q], accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accI[q] = Mfma<T>::mma(xi, ur[q], accI[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xi, ur[q], accI[q]);
             } else {                  // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr          (A = conj(u)^T, B = x)
                 const T nxr = -xr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accR[q] = Mfma<T>::mma(ur[q], xr, accR[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ur[q], xr, accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accI[q] = Mfma<T>::mma(ur[q], xi, accI[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ur[q], xi, accI[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accR[q] = Mfma<T>::mma(ui[q], xi, accR[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ui[q], xi, accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
             }
         }
 }
@@ -976,44 +944,11 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
         }
 }
 
-// FULL: `w0` is the origin of a full QW-wide window frame and `ww` packs the range of frame indices that belong to the real window
-// (klo | khi << 8): only those rows (left update) / columns (right update) are stored, the identity-padded rest is left untouched.
-template <class T, bool FULL = false>
+template <class T>
 __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, int w0, int ww, int lane, int pp, const typename Mfma<T>::acc_t (&accR)[2],
                                                 const typename Mfma<T>::acc_t (&accI)[2]) {
     const int lr = lane & 15;
     char* base = reinterpret_cast<char*>(d.X);       // scalar base + 32-bit byte offsets, as in slab_load_half
-    if constexpr (FULL) {
-        // one lane-dependent offset; the (r, q) part of every store is wave-uniform and moves into the scalar base
-        const int cr0 = Mfma<T>::crow(lane, 0), rs = Mfma<T>::crow(0, 1) - Mfma<T>::crow(0, 0);
-        const unsigned esz = (unsigned)sizeof(cx<T>);
-        const int klo = ww & 255, khi = ww >> 8;
-        if (d.side == 1) {
-            const unsigned lane_off = ((unsigned)(d.a0 + cr0) * n + w0 + lr) * esz;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool okr = d.a0 + cr0 + r * rs < d.lim;
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int k = 16 * (2 * pp + q2) + lr;
-                    char* pb = base + ((size_t)(r * rs) * n + 16 * (2 * pp + q2)) * esz;
-                    if (okr && k >= klo && k < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(accR[q2][r], accI[q2][r]);
-                }
-            }
-        } else {
-            const unsigned lane_off = ((unsigned)(w0 + cr0) * n + d.a0 + lr) * esz;
-            const bool okc = d.a0 + lr < d.lim;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int i = 16 * (2 * pp + q2) + cr0 + r * rs;
-                    char* pb = base + (size_t)(16 * (2 * pp + q2) + r * rs) * n * esz;
-                    if (okc && i >= klo && i < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(accR[q2][r], accI[q2][r]);
-                }
-        }
-        return;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cr = Mfma<T>::crow(lane, r);
@@ -1032,7 +967,7 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
     }
 }
 
-template <class T, int SIDE, bool FULL = false, bool BAND = false>
+template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]);
 
@@ -1042,11 +977,11 @@ __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __
     slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
     slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
-    slab_compute<T, SIDE, false, BAND>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+    slab_compute<T, SIDE, BAND>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
 }
 
 // multiply + store of one strip whose streamed operand is already in (or on its way to) registers
-template <class T, int SIDE, bool FULL, bool BAND>
+template <class T, int SIDE, bool BAND>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
     if constexpr (sizeof(T) == 8) {
@@ -1070,7 +1005,7 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
                     p1[q][r] = SIDE == 1 ? a - b : a + b;               // real part
                     p2[q][r] = SIDE == 1 ? c - a - b : c - a + b;       // imaginary part
                 }
-            slab_store_pair<T, FULL>(d, n, w0, ww, lane, pp, p1, p2);
+            slab_store_pair<T>(d, n, w0, ww, lane, pp, p1, p2);
         }
         return;
     }
@@ -1079,8 +1014,8 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { accR[q][r] = T(0); accI[q][r] = T(0); }
-    slab_multiply_half<T, SIDE>(Ur, Ui, 0, lane, xa, accR, accI);
-    slab_multiply_half<T, SIDE>(Ur, Ui, 1, lane, xb, accR, accI);
+    slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 0, lane, xa, accR, accI);
+    slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 1, lane, xb, accR, accI);
     slab_store<T>(d, n, w0, ww, lane, accR, accI);
 }
 
@@ -1108,227 +1043,103 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
     }
 }
 
-// Off-window updates of a window step.  With ONE chain per sweep (the default) a single launch does everything (PART 2: the
-// regions are disjoint).  With several chains two launches order the left updates (PART 0) before the right updates of H and Z
-// (PART 1), see the note at the top.  blockIdx.y = matrix, blockIdx.x = chain * nslab + strip group; a workgroup takes 4*SPW
-// consecutive strips of ONE chain (its 4 waves interleaved, so that they stream neighbouring rows).
-// SPW = strips per wave (a workgroup covers 4*SPW strips): 1 gives the shortest dependent chain per launch and the most
-// workgroups (what matters when several iteration groups keep the GPU busy with small launches); larger values amortise the
-// U prologue (64 KiB from L2 per workgroup) over more streamed data.
-// PART 2 claims its strips DYNAMICALLY (per-matrix counter QrState::strip_next, reset by the window kernel of the step): the
-// latency-bound kernels of the other iteration groups hold whole CUs (133 KB of LDS each), so a launch sized to fill the chip
-// exactly would otherwise run a second, nearly empty round of workgroups on the CUs that are left; with dynamic claiming a
-// workgroup that starts late finds the counter exhausted and leaves, and the launch ends when the work does.
-template <class T, int SPW, int PART>
-__global__ __launch_bounds__(256, 2) void apply_window_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
-                                                           QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall,
-                                                           unsigned* __restrict__ work, int nslab, int dynamic, int band_on, int wantz) {
+// The update kernels walk over LINKS of the sweep's log (QrLink: window [w0, w1), kind, e = first column the left update still has to
+// reach; the window unitary sits in the same slot of the U log, that of a dense link in the per-matrix buffer the prepare kernel writes).
+//
+// MODE 0 -- right behind a window step, links [q0, q0 + nq) of chain blockIdx.x / units:
+//     chase link:  H[w0:w1, e:n) <- U^H H[w0:w1, e:n)            (the left update: the next window's new columns are among these)
+//     dense link:  the same + H[0:w0, w0:w1) <- H[0:w0, w0:w1) U + Z[:, w0:w1) <- Z[:, w0:w1) U   (unitary of an AED window / a finished
+//                  block: the chase that follows reads rows above that window, so nothing of it can wait)
+//     A workgroup takes 4 * spw consecutive strips (its 4 waves interleaved, so that they stream neighbouring columns / rows).
+// MODE 1 -- links [q0, q0 + nq) x all chains, in order, chase links only (`units` = parts: bit 0 rows of H, bit 1 rows of Z):
+//     H[0:w0, w0:w1) <- H[0:w0, w0:w1) U   and   Z[:, w0:w1) <- Z[:, w0:w1) U.
+//     A workgroup owns 64 ROWS (one 16-row strip per wave) of Z (the first blocks) or of H and takes them through every link whose
+//     window lies below them: U_q is staged once per link, the strip's 16 x 64 block moves 31 columns to the right from link to link.
+//     ONE chain per sweep: once per sweep for both parts -- nothing else touches these rows x columns during the sweep (left updates act
+//     on rows INSIDE a window, and no window of the sweep comes back to rows above an earlier one), and left / right multiplications
+//     commute, so the result is that of the interleaved order.  SEVERAL chains: a following chain's window does come back to rows the
+//     chain ahead has updated from the right, so the H part runs after every window step (nq = 1) and only Z waits for the end of the sweep.
+template <class T, int MODE>
+__global__ __launch_bounds__(256, 2) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+                                                          const QrLink* __restrict__ links_all, const cx<T>* __restrict__ Ulog_all,
+                                                          const cx<T>* __restrict__ Udense_all, unsigned* __restrict__ work, int nslot, int kc,
+                                                          int q0, int nq, int spw, int units, int band_on) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
+    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);          // [4] per-wave votes, behind the planes
     const int b = blockIdx.y;
-    const int ch = blockIdx.x / nslab, gx = blockIdx.x - ch * nslab;
-    const int w0 = st_all[b].w0[ch], w1 = st_all[b].w1[ch];
-    const int ww = w1 - w0;
-    if (ww <= 0) return;
-    const SlabRanges RG = slab_ranges(st_all[b], n, w0, w1, wantz);
-    const int nL = RG.nL, nR = RG.nR, nZ = RG.nZ;
-    const int S = PART == 0 ? nL : (PART == 1 ? nR + nZ : nL + nR + nZ);
-    if (S <= 0) return;
-    const int g0 = gx * (4 * SPW);
-    if (PART == 2 && dynamic) { if (*(volatile int*)&st_all[b].strip_next >= S) return; }
-    else if (g0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
-    if (PART >= 1 && gx == 0 && t == 0)              // algorithmic work of this chain's update (both parts), in units of 4096 complex MACs
-        atomicAdd(work, (unsigned)(((long)ww * ww * (wantz ? 2L * n - ww : (long)(RG.lclim > w1 ? RG.lclim - w1 : 0) + (w0 - RG.rr0))) >> 12));
-    const cx<T>* U = Uall + ((long)b * QKC + ch) * QW * QW;
-    int dense = 0;                            // any nonzero in the blocks the banded product skips?
-    for (int e = t; e < QW * QW; e += 256) {
-        const int k = e >> 6, c = e & 63;
-        cx<T> u(T(0), T(0));
-        if (k < ww && c < ww) u = U[k * QW + c];
-        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
-        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
-    }
-    int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);          // [4] per-wave votes, behind the planes
-    { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
-    __syncthreads();
-    const bool band = sizeof(T) == 8 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
+    const int ch0 = MODE == 0 ? (int)blockIdx.x / units : 0;
+    const int gx = MODE == 0 ? (int)blockIdx.x - ch0 * units : (int)blockIdx.x;
+    const int unitsZ = (MODE == 1 && (units & 2)) ? (n + 63) >> 6 : 0;
+    const bool isZ = MODE == 1 && gx < unitsZ;
+    const int row0 = MODE == 1 ? 64 * (isZ ? gx : gx - unitsZ) : 0;     // MODE 1: first of this workgroup's 64 rows
     cx<T>* H = Aall + (long)b * mstride;
     cx<T>* Z = Zall + (long)b * mstride;
-    if (PART == 2 && dynamic) {
-        // dynamic claiming; the next claim is issued before the current strip is processed, so that the round trip of the atomic
-        // (1-2 us) hides behind a strip's worth of loads and MFMAs (a wave over-claims once at the end: harmless)
-        auto claim = [&]() {
-            int g = 0;
-            if (lane == 0) g = atomicAdd(&st_all[b].strip_next, 1);
-            return __builtin_amdgcn_readfirstlane(g);
-        };
-        for (int g = claim(); g < S;) {
-            const int gn = claim();
-            const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
-            if (band) {
-                if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
-                else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+    bool staged = false;                                              // LDS holds a U some wave may still be reading
+    for (int qq = q0; qq < q0 + nq; ++qq)
+        for (int ch = (MODE == 0 ? ch0 : 0); ch < (MODE == 0 ? ch0 + 1 : kc); ++ch) {
+            const QrLink* lp = links_all + ((long)b * nslot + qq) * kc + ch;
+            const int kind = __builtin_amdgcn_readfirstlane(lp->kind);
+            if (kind == QRL_NONE || (MODE == 1 && kind != QRL_CHASE)) continue;
+            const int w0 = __builtin_amdgcn_readfirstlane(lp->w0), w1 = __builtin_amdgcn_readfirstlane(lp->w1);
+            const int e = __builtin_amdgcn_readfirstlane(lp->e);
+            const int ww = w1 - w0;
+            if (ww <= 0) continue;
+            // strips of this link that fall to this workgroup (everything here is workgroup-uniform)
+            int nL = 0, nR = 0, nZ = 0, S = 0, g0 = 0;
+            if (MODE == 0) {
+                nL = n > e ? (n - e + 15) >> 4 : 0;
+                if (kind == QRL_DENSE) { nR = (w0 + 15) >> 4; nZ = (n + 15) >> 4; }
+                S = nL + nR + nZ;
+                g0 = gx * (4 * spw);
+                if (g0 >= S) continue;
             } else {
-                if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-                else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+                if (row0 >= (isZ ? n : w0)) continue;
             }
-            g = gn;
-        }
-        return;
-    }
-    for (int i = 0; i < SPW; ++i) {
-        const int g = g0 + wave + 4 * i;
-        if (g >= S) break;
-        const SlabStrip<T> d = slab_locate<T, PART>(g, RG, H, Z, n, w0);
-        const bool left = PART == 0 || (PART == 2 && d.side == 0);
-        if (band) {
-            if (left) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
-        } else {
-            if (left) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-            else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
-        }
-    }
-}
-
-// One 16x16 output tile (tile q of the strip) with the 3M product over the full K = QW, then its store: the unit of work of the
-// software-pipelined kernel below.  A single tile keeps only 24 accumulator registers live next to the two 64-register operand
-// buffers; the streamed operand is reused from registers by all four tiles, the U fragments come from LDS per tile.
-template <class T, int SIDE>
-__device__ __forceinline__ void slab_tile_3m(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int ws0, int krange, int lane, int q,
-                                             const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
-    const int lr = lane & 15, lk = lane >> 4;
-    typename Mfma<T>::acc_t p1, p2, p3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { p1[r] = T(0); p2[r] = T(0); p3[r] = T(0); }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 16 * q;
-                const cx<T> xv = h == 0 ? xa[4 * cc + j] : xb[4 * cc + j];
-                const T xs = xv.x + xv.y;
-                const T ur = Ur[off], ui = Ui[off];
-                if (SIDE == 1) {          // C = X U
-                    p1 = Mfma<T>::mma(xv.x, ur, p1);
-                    p2 = Mfma<T>::mma(xv.y, ui, p2);
-                    p3 = Mfma<T>::mma(xs, ur + ui, p3);
-                } else {                  // C = U^H X
-                    p1 = Mfma<T>::mma(ur, xv.x, p1);
-                    p2 = Mfma<T>::mma(ui, xv.y, p2);
-                    p3 = Mfma<T>::mma(ur - ui, xs, p3);
+            if (gx == 0 && t == 0)      // algorithmic work of this link's update, in units of 4096 complex MACs
+                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (kind == QRL_DENSE ? 2L * n - ww : (long)(n > e ? n - e : 0)))) >> 12));
+            const cx<T>* U = kind == QRL_DENSE ? Udense_all + (long)b * QW * QW : Ulog_all + (((long)b * nslot + qq) * kc + ch) * QW * QW;
+            if (staged) __syncthreads();                          // every wave is done with the previous link's planes
+            int dense = 0;                                        // any nonzero in the blocks the banded product skips?
+            for (int el = t; el < QW * QW; el += 256) {
+                const int k = el >> 6, c = el & 63;
+                cx<T> u(T(0), T(0));
+                if (k < ww && c < ww) u = U[k * QW + c];
+                Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+                if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
+            }
+            { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
+            __syncthreads();
+            staged = true;
+            const bool band = band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
+            if (MODE == 0) {
+                for (int i = 0; i < spw; ++i) {
+                    int g = g0 + wave + 4 * i;
+                    if (g >= S) break;
+                    SlabStrip<T> d;
+                    if (g < nL) { d.X = H; d.side = 0; d.a0 = e + 16 * g; d.lim = n; }
+                    else if (g < nL + nR) { d.X = H; d.side = 1; d.a0 = 16 * (g - nL); d.lim = w0; }
+                    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nL - nR); d.lim = n; }
+                    if (band) {
+                        if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
+                        else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+                    } else {
+                        if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
+                        else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+                    }
+                }
+            } else {
+                SlabStrip<T> d;
+                d.X = isZ ? Z : H; d.side = 1; d.a0 = row0 + 16 * wave; d.lim = isZ ? n : w0;
+                if (d.a0 < d.lim) {
+                    if (band) slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
+                    else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);       // bounds the hoisting of the U fragment reads (4 k-steps at a time)
         }
-    // Cr, Ci from the three products, then the store of the tile (frame indices outside [klo, khi) are identity padding: skipped)
-    const int cr0 = Mfma<T>::crow(lane, 0), rs = Mfma<T>::crow(0, 1) - Mfma<T>::crow(0, 0);
-    const unsigned esz = (unsigned)sizeof(cx<T>);
-    const int klo = krange & 255, khi = krange >> 8;
-    char* base = reinterpret_cast<char*>(d.X);
-    if (SIDE == 1) {
-        const unsigned lane_off = ((unsigned)(d.a0 + cr0) * n + ws0 + lr) * esz;
-        const int k = 16 * q + lr;
-        const bool okk = k >= klo && k < khi;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const T a = p1[r], bb = p2[r], c = p3[r];
-            char* pb = base + ((size_t)(r * rs) * n + 16 * q) * esz;
-            if (okk && d.a0 + cr0 + r * rs < d.lim) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(a - bb, c - a - bb);
-        }
-    } else {
-        const unsigned lane_off = ((unsigned)(ws0 + cr0) * n + d.a0 + lr) * esz;
-        const bool okc = d.a0 + lr < d.lim;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const T a = p1[r], bb = p2[r], c = p3[r];
-            const int i = 16 * q + cr0 + r * rs;
-            char* pb = base + (size_t)(16 * q + r * rs) * n * esz;
-            if (okc && i >= klo && i < khi) *reinterpret_cast<cx<T>*>(pb + lane_off) = cx<T>(a + bb, c - a + bb);
-        }
-    }
-}
-template <class T, int SIDE>
-__device__ __forceinline__ void slab_strip_tiles(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int ws0, int krange, int lane,
-                                                 const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) slab_tile_3m<T, SIDE>(Ur, Ui, d, n, ws0, krange, lane, q, xa, xb);
-}
-
-// Software-pipelined variant of the single-launch update (fp64, one chain, n >= 2 QW): the loads of the NEXT strip are issued
-// before the current one is multiplied (register double buffer: 2 x 64 operand registers + 48 accumulators of the 3M tile pairs),
-// so the matrix cores do not wait out an HBM round trip per strip -- alone on the chip the one-strip-at-a-time kernel ran at 39 %
-// of the time its MFMAs need (rocprofv3 timeline: 100 us for a launch whose matrix-core work is 39 us).  To keep ONE code path in
-// the register budget every window is treated as a full QW-wide frame: its origin is moved up when it would stick out of the
-// matrix (ws0 = min(w0, n - QW)) and U is embedded in an identity of size QW; loads need no clamp on the window index, and the
-// stores skip the identity rows / columns (slab_store_pair<FULL>), so nothing outside the real window is rewritten.
-template <class T>
-__global__ __launch_bounds__(256, 2) void apply_window_pipe_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
-                                                                QrState* __restrict__ st_all, const cx<T>* __restrict__ Uall, unsigned* __restrict__ work, int wantz) {
-    TRX_DYN_SMEM(smem);
-    T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
-    T* Ui = Ur + QW * MLD;
-    const int b = blockIdx.y;
-    const int w0 = st_all[b].w0[0], w1 = st_all[b].w1[0];
-    const int ww = w1 - w0;
-    if (ww <= 0) return;
-    const SlabRanges RG = slab_ranges(st_all[b], n, w0, w1, wantz);
-    const int S = RG.nL + RG.nR + RG.nZ;
-    if (S <= 0) return;
-    const int t = threadIdx.x, lane = t & 63;
-    if (blockIdx.x == 0 && t == 0)
-        atomicAdd(work, (unsigned)(((long)ww * ww * (wantz ? 2L * n - ww : (long)(RG.lclim > w1 ? RG.lclim - w1 : 0) + (w0 - RG.rr0))) >> 12));
-    const int ws0 = w0 < n - QW ? w0 : n - QW;          // origin of the QW-wide frame
-    const int sh = w0 - ws0;                            // the real window sits at frame indices [sh, sh + ww)
-    const int krange = sh | ((sh + ww) << 8);
-    const cx<T>* U = Uall + (long)b * QKC * QW * QW;
-    for (int e = t; e < QW * QW; e += 256) {
-        const int k = e >> 6, c = e & 63;
-        const int kk = k - sh, cc = c - sh;
-        cx<T> u(k == c ? T(1) : T(0), T(0));
-        if (kk >= 0 && kk < ww && cc >= 0 && cc < ww) u = U[kk * QW + cc];
-        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
-    }
-    __syncthreads();
-    cx<T>* H = Aall + (long)b * mstride;
-    cx<T>* Z = Zall + (long)b * mstride;
-    // STATIC strip assignment here (wave w of workgroup x takes strips x*4*spw + w + 4 i): a dynamic claim is an atomic with return,
-    // and hipcc waits for it with vmcnt(0) right where it is issued (its wave-level atomic optimiser reads the result back at once),
-    // which also waits out every prefetch load in flight -- seen in the ISA, and measured: no gain from the pipeline with it.  The
-    // prefetch is unconditional (a wave past its last strip re-reads that strip and discards it), so there is no branch between
-    // the issue of the loads and the MFMAs that hide them; the waits in front of the MFMAs are vmcnt(16..25), i.e. they leave the
-    // 16 loads of the next strip in flight.
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int spw = (S + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x);          // strips per wave
-    const int gbase = blockIdx.x * 4 * spw + wave;
-    const int gend = (blockIdx.x + 1) * 4 * spw < S ? (blockIdx.x + 1) * 4 * spw : S;     // this workgroup's strips: [blockIdx.x*4*spw, gend)
-    if (gbase >= gend) return;
-    SlabStrip<T> d0 = slab_locate<T, 2>(gbase, RG, H, Z, n, w0), d1 = d0;
-    cx<T> xa0[8], xb0[8], xa1[8], xb1[8];
-    slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
-    slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
-    for (int g = gbase;; g += 8) {
-        const int gb = g + 4, gc = g + 8;
-        d1 = slab_locate<T, 2>(gb < gend ? gb : g, RG, H, Z, n, w0);
-        slab_load_half<T, true>(d1, 0, n, ws0, QW, lane, xa1);
-        slab_load_half<T, true>(d1, 1, n, ws0, QW, lane, xb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d0.side == 0) slab_strip_tiles<T, 0>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
-        else slab_strip_tiles<T, 1>(Ur, Ui, d0, n, ws0, krange, lane, xa0, xb0);
-        if (gb >= gend) break;
-        d0 = slab_locate<T, 2>(gc < gend ? gc : gb, RG, H, Z, n, w0);
-        slab_load_half<T, true>(d0, 0, n, ws0, QW, lane, xa0);
-        slab_load_half<T, true>(d0, 1, n, ws0, QW, lane, xb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d1.side == 0) slab_strip_tiles<T, 0>(Ur, Ui, d1, n, ws0, krange, lane, xa1, xb1);
-        else slab_strip_tiles<T, 1>(Ur, Ui, d1, n, ws0, krange, lane, xa1, xb1);
-        if (gc >= gend) break;
-    }
 }
 
 template <class T>
@@ -1345,7 +1156,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, dyn = 0, wgs = 0, pipe = 0, band = 0, rotb = 0;      // dyn: 0 auto, 1 static strips, 2 dynamic; wgs: workgroups per slab launch
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1364,21 +1175,22 @@ static QrKnobs& qr_knobs() {
         q.nibble = geti("TRX_QR_NIBBLE", 0, 100, 100);
         q.moves = geti("TRX_QR_MOVES", 0, QAED, QAED_MOVES);
         q.chains = geti("TRX_QR_CHAINS", 1, QKC, 0);
-        q.dyn = geti("TRX_SLAB_DYN", 0, 2, 0);
-        q.wgs = geti("TRX_SLAB_WGS", 32, 4096, 0);
-        q.pipe = geti("TRX_SLAB_PIPE", 0, 2, 0);
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
-        q.rotb = geti("TRX_QR_ROTB", 0, 2, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
+        q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
     return k;
 }
 
+// Bulge chains per sweep and slots of the link log: the workspace layout (eig.hip) and the solver must agree on both.
+int qr_chains_for(int batch) { const QrKnobs& K = qr_knobs(); return K.chains ? K.chains : (batch <= 2 ? QKC : 1); }
+int qr_log_slots(int n) { return cdiv_i(n + 2 * QNS, QW - 2 * QNS - 1) + 2 + 4 * (QKC - 1) + 1; }
+
 // Non-blocking streams and timing-less events for the iteration groups, created on first use and kept for the life of the
 // process (per device); a call checks out what it needs and hands it back, so concurrent callers never share one.
 struct QrLane {
-    hipStream_t s = nullptr;
+    hipStream_t s = nullptr;           // the group's stream (null: the caller's)
     hipEvent_t ev = nullptr;           // fork / join / start stagger
     hipEvent_t evs[2] = {nullptr, nullptr};   // "summary of iteration k has landed in hsum[k % 2]"
     int* hsum = nullptr;               // pinned host memory, 2 x 4 ints
@@ -1418,11 +1230,8 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_aed") { slot = &k.aed; hi = QAED; }
     else if (s == "qr_nibble") { slot = &k.nibble; hi = 100; }
     else if (s == "qr_moves") { slot = &k.moves; hi = QAED; }
-    else if (s == "qr_rotb") { slot = &k.rotb; hi = 2; }
+    else if (s == "qr_rotb") { slot = &k.rotb; hi = 1; }
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
-    else if (s == "slab_dyn") { slot = &k.dyn; hi = 2; }
-    else if (s == "slab_wgs") { slot = &k.wgs; hi = 4096; }
-    else if (s == "slab_pipe") { slot = &k.pipe; hi = 2; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
@@ -1431,9 +1240,9 @@ int qr_set_knob(const char* key, int value) {
 }
 
 template <class T>
-int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info, int wantz) {
+int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info) {
     constexpr int LD = QW + 1;
-    if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // slab kernel: 32-bit byte offsets inside one matrix
+    if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // update kernels: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
     const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
     const size_t sma = sizeof(T) * 2 * QW * MLD + 16;        // + the four per-wave band votes
@@ -1447,11 +1256,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         std::lock_guard<std::mutex> lock(attr_mu);
         int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
         if (stt == 0) {
-            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 0>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 0>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 0>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 1>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 1, 2>, sma) ||
-                  set_max_dyn_smem((const void*)apply_window_kernel<T, 2, 2>, sma) || set_max_dyn_smem((const void*)apply_window_kernel<T, 4, 2>, sma) || set_max_dyn_smem((const void*)apply_window_pipe_kernel<T>, sma) ||
+            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) ||
+                  set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
             stt = r ? 2 : 1;
         }
@@ -1461,39 +1267,33 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
     if (hipMemsetAsync(B.summary, 0, sizeof(int) * 64, s) != hipSuccess) return TRX_ERR_LAUNCH;
     const int max_sweeps = 30 * n + 100;
-    // strips per wave of the slab kernel: small batches are latency bound and keep the shorter per-launch chain
-    const int spw = K.spw ? K.spw : (batch >= 64 ? 4 : 2);
+    // strips per wave of the per-step left update: small batches are latency bound and keep the shorter per-launch chain
+    const int spw = K.spw ? K.spw : (batch >= 64 ? 2 : 1);
     const int nstrip = cdiv_i(n, 16);
-    const int nslabL = cdiv_i(nstrip + 1, 4 * spw);          // workgroups per matrix and chain: left strips <= n/16 + 1
-    const int nslabR = cdiv_i(2 * nstrip + 1, 4 * spw);      // right-H strips <= n/16 + 1, Z strips = n/16
     const int adv = QW - 2 * QNS - 1;                        // guaranteed chain advance per window step
     // Bulge chains per sweep.  Measured on MI355X (n = 1922): 2 / 3 chains cut the outer iterations by only 31 / 36 % (the AED's
-    // deflation yield, not the shift count, paces the iteration) while the slab work grows by a third, and the two-launch
-    // update they need costs 10 % on its own: 26.5 (1 chain, one launch) vs 22.1 / 21.9 solves/s at batch 128, 12.1 vs 11.3 at
-    // batch 16.  One chain is the default for batches; a single large matrix (the topology-optimisation case, n = 5202, batch 1) has
-    // no slab work to protect and gains from the shorter chain: 5.62 s (1 chain, AED 48) -> 5.16 s (3 chains) -> 4.79 s (3 chains,
-    // AED 64) for the whole forward solve (profiles/r02_single_matrix_knobs.txt).
-    const int kc = K.chains ? K.chains : (batch <= 2 ? QKC : 1);
-    // software-pipelined slab kernel: knob slab_pipe = 2 switches it on.  Measured on MI355X at batch 128 it is NOT faster than the
-    // one-strip-at-a-time kernel with dynamically claimed strips (27.4-28.0 vs 28.4 solves/s): a launch of the latter already
-    // overlaps the loads of one wave with the MFMAs of its SIMD neighbour, and the static strips the pipeline needs bring back
-    // the tail of a launch that dynamic claiming removes.  Kept as an option (tests/test_eig.py runs both).
-    const bool pipe = sizeof(T) == 8 && n >= 2 * QW && K.pipe == 2;
+    // deflation yield, not the shift count, paces the iteration) while the update work grows by a third: one chain is the default for
+    // batches; a single large matrix (the topology-optimisation case, n = 5202, batch 1) has no update work to protect and gains from the
+    // shorter chain: 5.62 s (1 chain, AED 48) -> 5.16 s (3 chains) -> 4.79 s (3 chains, AED 64) for the whole forward solve
+    // (profiles/r02_single_matrix_knobs.txt).
+    const int kc = qr_chains_for(batch);
+    const int nslot = qr_log_slots(n);
     const int band_on = K.band != 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
-    // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the slab updates
-    // of the other groups fill the matrix cores.  One host thread drives all of them round-robin; per visit it reads the 16-byte
+    // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
+    // of the other groups fill the matrix cores.  One host thread drives all of them; per visit it reads the 12-byte
     // summary of the group's last prepare (normally long finished: the prepare is queued right behind the group's sweep),
     // queues the next sweep and the prepare after it, and moves on.
     constexpr int MAXG = 8;
     struct Group {
-        QrLane lane;           // stream (null: the caller's) + event
+        QrLane lane;           // streams + events
         hipStream_t s;
         int b0, nb;
-        int* summary;          // device, 8 ints: two slots {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] slab work (cumulative)
+        int* summary;          // device, 8 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
+                               // per-step / the deferred updates (cumulative, in units of 4096 complex MACs)
         bool done;
-        unsigned work;
+        unsigned work[2];
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
@@ -1519,7 +1319,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.done = false;
         G.issued = 0;
         G.read = 0;
-        G.work = 0;
+        G.work[0] = G.work[1] = 0;
         G.par = 0;
         G.g = g;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
@@ -1527,7 +1327,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
-    // AED window: 64 deflates most per call (fewest sweeps, least slab work) but costs 3 ms of single-wave latency; at small
+    // AED window: 64 deflates most per call (fewest sweeps, least update work) but costs 3 ms of single-wave latency; at small
     // batches, where nothing is throughput bound, a smaller window shortens the chain
     const long mstride = (long)ngroups * n * n;              // distance between consecutive matrices of one group
     const int aed_w = K.aed ? K.aed : ((batch >= 64 || batch <= 2) ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48; batch 1 with 3 chains: 64
@@ -1538,71 +1338,59 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const bool qr_debug = K.debug;                                        // cycle breakdown of the prepare / window kernels (matrix 0) to stderr
     long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 64);    // 24 counters behind the group summaries
     // One outer iteration of a group = the window steps of its sweep followed by the next prepare (deflation scan, AED, shifts)
-    // and the copy of that prepare's 16-byte summary into pinned host memory.  The host runs ONE ITERATION AHEAD of what it has
+    // and the copy of that prepare's 12-byte summary into pinned host memory.  The host runs ONE ITERATION AHEAD of what it has
     // read: iteration k+1 is queued with a step count from summary k-1 -- summary[1] is an upper bound (ihi + 1) for every block
     // the matrices of the group can still work on, and it only shrinks; a step a chain does not need is a kernel that exits at
-    // once.  So a stream never drains while the host is busy with another group (with one queued iteration per group and a
-    // blocking read the groups ran mostly ONE AT A TIME: rocprofv3 timeline, profiles/).
+    // once.  So a stream never drains while the host is busy with another group.
     auto issue_prepare = [&](Group& G, int slot) -> bool {
         int* sum = G.summary + 4 * slot;
-        if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (slab work) keeps accumulating
+        if (hipMemsetAsync(sum, 0, sizeof(int) * 3, G.s) != hipSuccess) return false;            // G.summary[3] (update work) keeps accumulating
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
           if (K.rotb == 1)
-              TRX_LAUNCH((qr_prepare_kernel<T, false>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
+              TRX_LAUNCH((qr_prepare_kernel<T, false>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QW * QW,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
                          (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
           else
-              TRX_LAUNCH((qr_prepare_kernel<T, true>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QKC * QW * QW,
-                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, wantz,
+              TRX_LAUNCH((qr_prepare_kernel<T, true>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QW * QW,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
                          (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
     };
-    auto issue_sweep = [&](Group& G, int bound) {
+    auto issue_sweep = [&](Group& G, int bound) -> bool {
         cx<T>* Ag = B.A + (long)G.g * n * n;
         cx<T>* Zg = B.Z + (long)G.g * n * n;
-        cx<T>* Ug = B.U + (long)G.b0 * QKC * QW * QW;
+        const cx<T>* Ud = B.U + (long)G.b0 * QW * QW;
+        cx<T>* Ul = B.Ulog + (long)G.b0 * nslot * kc * QW * QW;
+        QrLink* lk = B.links + (long)G.b0 * nslot * kc;
         const cx<T>* shg = B.shifts + (long)G.b0 * QKC * QNS;
         QrState* stg = B.st + G.b0;
         // window steps: the first chain needs (m + 2 QNS) / adv steps (+ one slot that applies the AED unitary); every further chain
         // enters about 3 steps behind the one ahead.  `bound` is one iteration old, i.e. already a step or so generous, and a sweep
         // that still falls short is finished by the next iteration's steps (flag 2 of the summary).
-        const int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
+        int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
+        if (nwin > nslot) nwin = nslot;
         unsigned* wk = (unsigned*)(G.summary + 3);
         for (int q = 0; q < nwin; ++q) {
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ug, shg, G.par, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, (long long*)nullptr); }
             G.par ^= 1;
-            { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-              // single-launch variant: strips are claimed dynamically, so the workgroup count per matrix only has to fill the chip
-              // (about two workgroups per CU over the group), whatever the group size
-              // (groups of fewer than 16 matrices are latency bound and nothing competes for their CUs: static strips, measured faster)
-              const int dyn = K.dyn ? K.dyn - 1 : (G.nb >= 16);
-              int wgm = cdiv_i(2 * nstrip + 2, 4 * spw);
-              if (dyn) {
-                  wgm = (K.wgs ? K.wgs : 512) / G.nb;
-                  wgm = wgm < 1 ? 1 : (wgm > 32 ? 32 : wgm);      // > 32 per matrix: the 64 KB U prologue of each workgroup dominates (measured)
-                  if (wgm > cdiv_i(2 * nstrip + 2, 4)) wgm = cdiv_i(2 * nstrip + 2, 4);
-              }
-              const dim3 gl(kc * nslabL, G.nb), gr(kc * nslabR, G.nb), ga(wgm, G.nb);
-              if (kc == 1 && dyn && pipe) {
-                  if constexpr (sizeof(T) == 8) TRX_LAUNCH((apply_window_pipe_kernel<T>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wantz);
-              } else if (kc == 1) {
-                  if (spw == 1) TRX_LAUNCH((apply_window_kernel<T, 1, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
-                  else if (spw == 2) TRX_LAUNCH((apply_window_kernel<T, 2, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
-                  else TRX_LAUNCH((apply_window_kernel<T, 4, 2>), ga, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, wgm, dyn, band_on, wantz);
-              } else if (spw == 1) {
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
-                  TRX_LAUNCH((apply_window_kernel<T, 1, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
-              } else if (spw == 2) {
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
-                  TRX_LAUNCH((apply_window_kernel<T, 2, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
-              } else {
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 0>), gl, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabL, 0, band_on, wantz);
-                  TRX_LAUNCH((apply_window_kernel<T, 4, 1>), gr, dim3(256), sma, G.s, Ag, Zg, mstride, n, stg, (const cx<T>*)Ug, wk, nslabR, 0, band_on, wantz);
-              } }
+            { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
+              // slot 0 may carry a dense link (left | right-H | Z: up to 3 n / 16 + 3 strips), the others only left updates (<= n / 16 + 1 strips)
+              const int units = cdiv_i(q == 0 ? 3 * nstrip + 3 : nstrip + 1, 4 * spw);
+              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, 1, spw, units, band_on);
+              // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed)
+              if (kc > 1)
+                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, 1, 1, 1, band_on); }
         }
+        // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
+        // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
+        // deflation), so it cannot run beside it.
+        { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
+          const int parts = kc > 1 ? 2 : 3;
+          TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
+        return true;
     };
     if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
     // iteration 0 = the first prepare (chained: group g starts when group g-1 has finished its own, so that the groups start out of
@@ -1617,8 +1405,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     }
     for (int g = 0; g < ngroups && !rc; ++g) {
         Group& G = grp[g];
-        issue_sweep(G, n);
-        if (!issue_prepare(G, 1)) rc = TRX_ERR_LAUNCH;
+        if (!issue_sweep(G, n) || !issue_prepare(G, 1)) rc = TRX_ERR_LAUNCH;
         G.issued = 2;
     }
     // The host serves whichever group's summary has landed (event query), never a fixed round-robin with a blocking wait: a group
@@ -1641,8 +1428,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             ++G.read;
             if (active == 0) { G.done = true; --live; continue; }       // (the iteration already queued behind it finds nothing to do)
             // summary G.read-1 is in: queue iteration G.issued (slot parity = G.issued & 1 = slot, free again now)
-            issue_sweep(G, bound);
-            if (!issue_prepare(G, G.issued & 1)) { rc = TRX_ERR_LAUNCH; break; }
+            if (!issue_sweep(G, bound) || !issue_prepare(G, G.issued & 1)) { rc = TRX_ERR_LAUNCH; break; }
             ++G.issued;
         }
         if (rc) break;
@@ -1656,11 +1442,13 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (gmin >= 0 && hipEventSynchronize(grp[gmin].lane.evs[grp[gmin].read & 1]) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
     (void)hipGetLastError();          // hipEventQuery leaves hipErrorNotReady as the thread's last error
-    double work = 0;
+    double work[2] = {0, 0};
     for (int g = 0; g < nlanes; ++g) {
         Group& G = grp[g];
-        if (!rc && prof_enabled() && hipMemcpyAsync(&G.work, G.summary + 3, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess)
-            work += G.work;
+        if (!rc && prof_enabled() && hipMemcpyAsync(&G.work[0], G.summary + 3, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess &&
+            hipMemcpyAsync(&G.work[1], G.summary + 7, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess) {
+            work[0] += G.work[0]; work[1] += G.work[1];
+        }
         if (g > 0) {
             // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
             if (hipEventRecord(G.lane.ev, G.s) != hipSuccess || hipStreamWaitEvent(s, G.lane.ev, 0) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
@@ -1682,13 +1470,16 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                             "reorder %lld | restore %lld | store %lld || window kernel: load %lld chase %lld (%lld chain steps) store %lld; per phase: rotg %lld left %lld barrier %lld right %lld barrier %lld\n",
                     h[11], h[6], h[7], h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[12], h[13], h[15], h[14], h[16], h[17], h[18], h[19], h[20]);
     }
-    if (prof_enabled()) prof_add_work(PROF_QR_APPLY_RIGHT, 8.0 * 4096.0 * work, 0.0);
+    if (prof_enabled()) {      // algorithmic work of the update kernels: 8 flops per complex MAC, every element of a 64-wide slab read and written once
+        prof_add_work(PROF_QR_APPLY_LEFT, 8.0 * 4096.0 * work[0], 2.0 * sizeof(cx<T>) * 4096.0 * work[0] / QW);
+        prof_add_work(PROF_QR_APPLY_RIGHT, 8.0 * 4096.0 * work[1], 2.0 * sizeof(cx<T>) * 4096.0 * work[1] / QW);
+    }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch, ngroups);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
 
-template int hessenberg_qr<float>(hipStream_t, const EigBuffers<float>&, int, int, int*, int);
-template int hessenberg_qr<double>(hipStream_t, const EigBuffers<double>&, int, int, int*, int);
+template int hessenberg_qr<float>(hipStream_t, const EigBuffers<float>&, int, int, int*);
+template int hessenberg_qr<double>(hipStream_t, const EigBuffers<double>&, int, int, int*);
 
 }  // namespace trx

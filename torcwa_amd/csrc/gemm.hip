@@ -172,178 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     }
 }
 
-// ---- fp64 general tile with the operands streamed by direct global -> LDS loads ------------------------------------------------------
-// The register-staged kernel above tops out at 73 TF-equivalent (70 % of the 3M ceiling): a 16-deep K slab is 48 MFMAs per wave (1.3 us),
-// shorter than the round trip of the register prefetch of the next slab under load, a deeper slab or a second register stage does not fit in
-// 256 VGPRs next to the 96 accumulator registers, and every slab costs two barriers and 16 LDS stores per thread.  Here a ring of GST
-// stages of GBK = 8 k-values lives in LDS, filled by global_load_lds_dwordx4 (TRX_LDS_DMA16: no destination registers, no LDS store
-// instructions, GST - 1 slabs ahead); one barrier per slab.  LDS holds INTERLEAVED complex elements, placed by the lane -> address map of
-// the loads (lane L of a load lands at chunk base + 16 L, so any gather is free):
-//   operand whose k index is contiguous in memory (A of op N, B of op T / C):  [major][GBK + 1]  (one pad element per row: the b128 fragment
-//                                                    reads of 8 consecutive rows fall into 8 distinct bank quads)
-//   operand whose major index is contiguous (A of op T / C, B of op N):       [GBK][major]
-// one ds_read_b128 per fragment delivers (re, im); conjugation is a sign flip on the fragment.  The K tail is masked on the A fragment
-// (clamped loads read finite data; 0 x finite = 0), rows / columns beyond the matrix only feed outputs that are never stored.
-constexpr int GBK = 8, GST = 4;
-
-template <int OPA, int OPB, int WR, int NT>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(int m, int n, int k, cx<double> alpha, const cx<double>* __restrict__ A, int lda, long sA,
-                                                       const cx<double>* __restrict__ B, int ldb, long sB, cx<double> beta, cx<double>* __restrict__ C,
-                                                       int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
-    typedef double T;
-    constexpr int WC = 4 / WR, BM = 16 * WR, BN = 16 * NT * WC;
-    constexpr bool A_KC = (OPA == TRX_OP_N), B_KC = (OPB != TRX_OP_N);
-    constexpr int SA = A_KC ? BM * (GBK + 1) : GBK * BM, SB = B_KC ? BN * (GBK + 1) : GBK * BN;     // slots (elements) of the A / B part of a stage
-    constexpr int CA = (SA + 63) / 64, CB = (SB + 63) / 64;                                           // 64-slot chunks = load instructions
-    constexpr int NI = (CA + CB + 3) / 4;                                                             // load instructions per wave and slab
-    constexpr int STG = (CA + CB) * 64;                                                               // stage, in elements
-    TRX_DYN_SMEM(smem);
-    cx<T>* ring = reinterpret_cast<cx<T>*>(smem);                   // [GST][STG] + one scratch chunk for the padding loads
-    cx<T>* scratch = ring + GST * STG;
-    const int b = blockIdx.z;
-    A += (long)b * sA;
-    B += (long)b * sB;
-    C += (long)b * sC;
-    if (desc) {
-        const GemmDesc d = desc[b];
-        m = d.m; n = d.n; k = d.k;
-        A += d.offA; B += d.offB; C += d.offC;
-    }
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (m0 >= m || n0 >= n) return;
-    if (b_upper && n0 + BN < k) k = n0 + BN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
-    const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    // per wave and slab: chunks wave, wave + 4, ...; what a lane fetches for chunk c follows from its LDS slot p = 64 c' + lane
-    const cx<T>* gsrc[NI];        // address of this lane's element in slab 0 (clamped rows / columns)
-    int gkk[NI];                  // its k offset inside the slab (GBK for a pad slot / padding load: re-reads k offset 0)
-    unsigned ldst[NI];            // LDS element offset of the chunk inside a stage (or the scratch chunk)
-    long gstep[NI];               // element distance between slabs
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = wave + 4 * i;
-        if (c < CA) {
-            const int p = 64 * c + lane;
-            int row, kk;
-            if (A_KC) { row = p / (GBK + 1); kk = p - row * (GBK + 1); } else { kk = p / BM; row = p - kk * BM; }
-            if (row >= BM) row = BM - 1;
-            if (kk >= GBK) kk = 0;
-            const int gr = m0 + row < m ? m0 + row : m - 1;
-            gsrc[i] = (OPA == TRX_OP_N) ? A + (long)gr * lda : A + gr;
-            gkk[i] = kk;
-            gstep[i] = (OPA == TRX_OP_N) ? 1 : lda;
-            ldst[i] = 64 * c;
-        } else if (c < CA + CB) {
-            const int p = 64 * (c - CA) + lane;
-            int col, kk;
-            if (B_KC) { col = p / (GBK + 1); kk = p - col * (GBK + 1); } else { kk = p / BN; col = p - kk * BN; }
-            if (col >= BN) col = BN - 1;
-            if (kk >= GBK) kk = 0;
-            const int gc = n0 + col < n ? n0 + col : n - 1;
-            gsrc[i] = (OPB == TRX_OP_N) ? B + gc : B + (long)gc * ldb;
-            gkk[i] = kk;
-            gstep[i] = (OPB == TRX_OP_N) ? ldb : 1;
-            ldst[i] = 64 * c;
-        } else {
-            gsrc[i] = A; gkk[i] = 0; gstep[i] = 0; ldst[i] = GST * STG;      // padding load: keeps the per-wave instruction count uniform
-        }
-    }
-    auto issue = [&](int slab) __attribute__((always_inline)) {
-        const int k0 = slab * GBK;
-        cx<T>* stage = ring + (slab % GST) * STG;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int kg = k0 + gkk[i] < k ? k0 + gkk[i] : k - 1;           // clamped: finite data, masked at the A fragment
-            cx<T>* dst = ldst[i] == (unsigned)(GST * STG) ? scratch : stage + ldst[i];
-            TRX_LDS_DMA16(gsrc[i] + (long)kg * gstep[i], dst);
-        }
-    };
-    typename Mfma<T>::acc_t p1[NT], p2[NT], p3[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { p1[j][r] = T(0); p2[j][r] = T(0); p3[j][r] = T(0); }
-    const int arow0 = 16 * (wave % WR), bcol0 = 16 * NT * (wave / WR);
-    const int lr = lane & 15, lk = lane >> 4;
-    const int nslab = (k + GBK - 1) / GBK;
-#pragma unroll
-    for (int sl = 0; sl < GST - 1; ++sl)
-        if (sl < nslab) issue(sl);
-    for (int sl = 0; sl < nslab; ++sl) {
-        // slab sl has landed when at most the loads of the younger slabs (up to GST - 2 of them) are still in flight
-        const int younger = nslab - 1 - sl < GST - 2 ? nslab - 1 - sl : GST - 2;
-        if (younger >= 2) TRX_WAIT_VMCNT_N(NI * 2 <= 15 ? NI * 2 : 15);
-        else if (younger == 1) TRX_WAIT_VMCNT_N(NI);
-        else TRX_WAIT_VMCNT(0);
-        __syncthreads();
-        if (sl + GST - 1 < nslab) issue(sl + GST - 1);                   // into the stage slab sl - 1 was read from (everybody is past it)
-        const cx<T>* As = ring + (sl % GST) * STG;
-        const cx<T>* Bs = As + CA * 64;
-#pragma unroll
-        for (int ks = 0; ks < GBK; ks += 4) {
-            const int kk = ks + lk;
-            cx<T> a = A_KC ? As[(arow0 + lr) * (GBK + 1) + kk] : As[kk * BM + arow0 + lr];
-            const bool kin = sl * GBK + kk < k;
-            T ar = kin ? a.x : T(0), ai = kin ? a.y : T(0);
-            if (OPA == TRX_OP_C) ai = -ai;
-            const T as = ar + ai;
-            T br[NT], bi[NT], bs[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = bcol0 + 16 * j + lr;
-                const cx<T> bv = B_KC ? Bs[col * (GBK + 1) + kk] : Bs[kk * BN + col];
-                br[j] = bv.x; bi[j] = (OPB == TRX_OP_C) ? -bv.y : bv.y;
-                bs[j] = br[j] + bi[j];
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) p1[j] = Mfma<T>::mma(ar, br[j], p1[j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) p2[j] = Mfma<T>::mma(ai, bi[j], p2[j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) p3[j] = Mfma<T>::mma(as, bs[j], p3[j]);
-        }
-    }
-    const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
-    cx<T> cv[4][NT];
-    if (has_beta) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + arow0 + Mfma<T>::crow(lane, r);
-            const int rc = row < m ? row : m - 1;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = n0 + bcol0 + 16 * j + lr;
-                cv[r][j] = C[(long)rc * ldc + (col < n ? col : n - 1)];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + arow0 + Mfma<T>::crow(lane, r);
-        if (row >= m) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + bcol0 + 16 * j + lr;
-            if (col >= n) continue;
-            const T a1 = p1[j][r], a2 = p2[j][r];
-            cx<T> v = alpha * cx<T>(a1 - a2, p3[j][r] - a1 - a2);
-            if (has_beta) v += beta * cv[r][j];
-            C[(long)row * ldc + col] = v;
-        }
-    }
-}
-
-// Measured on MI355X (round 3, profiles/r03_gemm_ring.txt): the ring kernel runs at EXACTLY the rate of the register-staged one (73.7 vs
-// 73.3 TF-equivalent at 1922^3 x 128, 79.5 vs 80.1 at 4096^3, 29.7 vs 29.9 layer-solves/s in the bench) -- neither the load latency nor the
-// LDS stores nor the second barrier is what holds the 3M product at ~76 % of the matrix-core peak in issued MFMAs.  Default: off.
-static int gemm_dma_env() { const char* e = getenv("TRX_GEMM_DMA"); return (e && atoi(e) == 1) ? 1 : 0; }
-// Large-tile fp64 kernel of gemm_big.hip: trx_tuning("gemm_big", v) / TRX_GEMM_BIG, v = 0 automatic (= 3), 1 .. 3 tile configuration
-// (1: 96 x 96 and 2: 128 x 80 with one wave per SIMD and AGPR-pinned accumulators; 3: 128 x 96 with 8 waves), 4 = off (64 x 64 tile
-// of this file).  Measured on MI355X at 1922^3 x 128 (profiles/r04_ab/r4_gemm_big.txt): 73.2 (off) / 79.2 / 80.2 / 83.2 TF-equivalent.
-static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }
+// Large-tile fp64 kernel of gemm_big.hip (128 x 96 on 8 waves): trx_tuning("gemm_big", v) / TRX_GEMM_BIG, v = 0 automatic (= on), 4 = off (64 x 64
+// tile of this file everywhere).  Measured on MI355X at 1922^3 x 128 (profiles/r04_ab/r4_gemm_big.txt): 73.2 (off) / 85.2 TF-equivalent.
+static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 4) ? v : 0; }
 static int g_gemm_big = gemm_big_env();
-static inline int gemm_big_cfg() { return g_gemm_big == 0 ? 3 : (g_gemm_big == 4 ? 0 : g_gemm_big); }
-static int g_gemm_dma = gemm_dma_env();       // trx_tuning("gemm_dma", 0 / 1): fp64 general tile through the direct-to-LDS ring (TRX_GEMM_DMA)
 
 template <class T, int OPA, int OPB>
 void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
@@ -355,18 +187,6 @@ void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T
     else if (shape == 2)
         TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else {
-        if constexpr (sizeof(T) == 8) {
-            if (g_gemm_dma) {
-                constexpr bool A_KC = (OPA == TRX_OP_N), B_KC = (OPB != TRX_OP_N);
-                constexpr int SA = A_KC ? 64 * (GBK + 1) : GBK * 64, SB = B_KC ? 64 * (GBK + 1) : GBK * 64;
-                constexpr int STG = ((SA + 63) / 64 + (SB + 63) / 64) * 64;
-                const size_t sm = sizeof(cx<double>) * ((size_t)GST * STG + 64);
-                static bool attr_done = false;       // > 64 KB of dynamic LDS: opt in once per instantiation
-                if (!attr_done) { (void)set_max_dyn_smem((const void*)gemm_dma_kernel<OPA, OPB, 4, 4>, sm); attr_done = true; }
-                TRX_LAUNCH((gemm_dma_kernel<OPA, OPB, 4, 4>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), sm, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
-                return;
-            }
-        }
         TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     }
 }
@@ -387,13 +207,11 @@ int launch_b(hipStream_t s, int opB, int shape, int batch, int m, int n, int k, 
 
 int gemm_set_knob(const char* key, int value) {
     if (std::string(key) == "gemm_big") {
-        if (value < 0 || value > 4) return TRX_ERR_ARG;
+        if (value != 0 && value != 4) return TRX_ERR_ARG;
         g_gemm_big = value;
         return TRX_OK;
     }
-    if (std::string(key) != "gemm_dma" || value < 0 || value > 1) return TRX_ERR_ARG;
-    g_gemm_dma = value;
-    return TRX_OK;
+    return TRX_ERR_ARG;
 }
 
 template <class T>
@@ -423,14 +241,14 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
         // block tile: 1922 = 15 x 128 + 2 = 20 x 96 + 2) is peeled off for the flat / narrow tiles of this file instead of costing a
         // whole row / column of almost empty large tiles.
         int bm = 0, bn = 0;
-        const int big = gemm_big_cfg();
-        if (big) gemm_big_tile(big, &bm, &bn);
+        const int big = g_gemm_big != 4;
+        if (big) gemm_big_tile(&bm, &bn);
         // (its direct loads address an operand with 32-bit BYTE offsets from a scalar base: the operand's extent must stay below 4 GiB)
         const long exA = (long)(opA == TRX_OP_N ? m : k) * lda, exB = (long)(opB == TRX_OP_N ? k : n) * ldb;
         if (big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64 && exA < (1L << 28) && exB < (1L << 28)) {
             const int rm = (m % bm) <= 32 ? m % bm : 0, rn = (n % bn) <= 32 ? n % bn : 0;
             const int mm = m - rm, nm = n - rn;
-            int rc = gemm_big(s, big, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);
+            int rc = gemm_big(s, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);
             if (rc != TRX_OK) return rc;
             if (rm) {      // bottom rows, all columns
                 const cx<T>* Ar = A + (opA == TRX_OP_N ? (long)mm * lda : (long)mm);

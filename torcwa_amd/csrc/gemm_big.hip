@@ -1,12 +1,13 @@
 // Large-tile complex128 GEMM for the square products of the hot path (refinement, S-matrix stage, LU trailing updates; the call sites of
-// gemm.hip): C = alpha op(A) op(B) + beta C with a 128 x 96 block tile, ONE wave per SIMD.
+// gemm.hip): C = alpha op(A) op(B) + beta C with a 128 x 96 block tile on 8 waves (two per SIMD).
 //
 // Why a second kernel.  The 64 x 64 tile of gemm.hip moves 32 KB of operands per 64 x 64 x 16 complex MACs (16 flop/B in the 8-flops-per-MAC
 // count) and measured 73-74 TF-equivalent on 1922^3 x 128 however its operands arrive (register-staged, direct-to-LDS ring, true prefetch:
 // profiles/r03_gemm_ring.txt, profiles/r04_ab/r4_ab_chain.txt), with 17x the algorithmic bytes crossing the L2 -> fabric boundary (PMC).
 // A tile has to be larger to need fewer bytes per flop, and the 3M product needs three accumulators per 16 x 16 output tile (24 registers),
-// so a larger tile does not fit next to a second wave on the SIMD.  Here a workgroup is 4 waves = one per SIMD, each wave owns 64 x 48
-// (4 x 3 MFMA tiles = 288 accumulator registers of the SIMD's 512), and what the second wave used to hide is hidden by the wave itself:
+// so the tile is bounded by the register file: here a workgroup is 8 waves = two per SIMD, each wave owns 32 x 48 (2 x 3 MFMA tiles = 144
+// accumulator registers, VGPR form of the MFMA), and the instruction order of a wave is written down slot by slot.  (The one-wave-per-SIMD
+// layouts of round 4 -- 96 x 96 / 128 x 80 with AGPR-pinned accumulators -- measured 79-80 against 85 TF-equivalent and were removed.)
 //   * operands arrive by global_load_lds_dwordx4 into a ring of GST stages of GBK k-values, GST - 1 slabs ahead: no staging registers, no
 //     LDS stores, loads in flight across barriers;
 //   * fragments are double-buffered in registers: the ds_read_b128 of k-step s + 1 are issued in front of the 36 MFMAs of k-step s;
@@ -25,6 +26,7 @@
 #include "prof.hpp"
 
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 
 namespace trx {
@@ -53,9 +55,7 @@ struct BigCfg {
     static constexpr size_t smem = sizeof(cx<double>) * ((size_t)QST * STG + 64);                  // + one scratch chunk for padding loads
 };
 
-// PIN: accumulators pinned to AGPRs (one wave per SIMD, up to 256 accumulator registers); otherwise ordinary values, for the 8-wave
-// layouts whose 144 accumulator registers fit the VGPR form of the MFMA next to a second wave on the SIMD
-template <int OPA, int OPB, int WM, int WN, int QTM, int QTN, bool PIN>
+template <int OPA, int OPB, int WM, int WN, int QTM, int QTN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(int m, int n, int k, cx<double> alpha, const cx<double>* __restrict__ A, int lda, long sA,
                                                       const cx<double>* __restrict__ B, int ldb, long sB, cx<double> beta, cx<double>* __restrict__ C,
                                                       int ldc, long sC, int b_upper) {
@@ -181,19 +181,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
         TRX_WAIT_VMCNT(0);
         return;
     }
-    // accumulators: P1, P2, P3 of MFMA tile (i, j) are the pinned accumulators 3 (i QTN + j) + 0 / 1 / 2 (common.hpp)
-    TRX_ACC_DECL(NMF);
-    typename Mfma<T>::acc_t pacc[PIN ? 1 : NMF];
+    // accumulators: P1, P2, P3 of MFMA tile (i, j) are pacc[3 (i QTN + j) + 0 / 1 / 2]
+    typename Mfma<T>::acc_t pacc[NMF];
     static_for<NMF>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        if constexpr (PIN) TRX_ACC_ZERO(q);
-        else pacc[q] = typename Mfma<T>::acc_t{T(0), T(0), T(0), T(0)};
+        pacc[q] = typename Mfma<T>::acc_t{T(0), T(0), T(0), T(0)};
     });
     auto mfma_one = [&](int set, auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value, tile = q / 3, part = q % 3, i = tile / QTN, j = tile % QTN;
-        const T av = fa[set][i][part], bv = fb[set][j][part];         // (locals: an asm operand alone does not capture in a generic lambda)
-        if constexpr (PIN) TRX_ACC_MFMA(q, av, bv);
-        else pacc[q] = Mfma<T>::mma(av, bv, pacc[q]);
+        pacc[q] = Mfma<T>::mma(fa[set][i][part], fb[set][j][part], pacc[q]);
     };
     {
         const cx<T>* st = ring;
@@ -226,7 +222,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
         });
     }
     TRX_WAIT_VMCNT(0);                                                        // no direct-to-LDS load may outlive the workgroup's LDS allocation
-    if constexpr (PIN) TRX_ACC_DRAIN();                                      // the last MFMAs have written their accumulators
 
     // ---- epilogue: C = alpha (P1 - P2, P3 - P1 - P2) + beta C, one row tile at a time (12 C elements per lane in flight)
     const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
@@ -248,14 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
         static_for<4 * QTN>([&](auto rjc) {
             constexpr int r = decltype(rjc)::value / QTN, j = decltype(rjc)::value % QTN;
             const int row = m0 + arow0 + 16 * i + Mfma<T>::crow(lane, r), col = n0 + bcol0 + 16 * j + lr;
-            T a1, a2, a3;
-            if constexpr (PIN) {
-                TRX_ACC_READ(3 * (i * QTN + j), r, a1);
-                TRX_ACC_READ(3 * (i * QTN + j) + 1, r, a2);
-                TRX_ACC_READ(3 * (i * QTN + j) + 2, r, a3);
-            } else {
-                a1 = pacc[3 * (i * QTN + j)][r]; a2 = pacc[3 * (i * QTN + j) + 1][r]; a3 = pacc[3 * (i * QTN + j) + 2][r];
-            }
+            const T a1 = pacc[3 * (i * QTN + j)][r], a2 = pacc[3 * (i * QTN + j) + 1][r], a3 = pacc[3 * (i * QTN + j) + 2][r];
             cx<T> v = alpha * cx<T>(a1 - a2, a3 - a1 - a2);
             if (has_beta) v += beta * cv[r][j];
             if (row < m && col < n) C[(long)row * ldc + col] = v;
@@ -263,56 +251,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
     });
 }
 
-template <int OPA, int OPB, int WM, int WN, int QTM, int QTN, bool PIN>
+template <int OPA, int OPB, int WM, int WN, int QTM, int QTN>
 int launch_big(hipStream_t s, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb, long sB,
                cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
     typedef BigCfg<OPA, OPB, WM, WN, QTM, QTN> Cfg;
-    static bool attr_done = false;       // > 64 KB of dynamic LDS: opt in once per instantiation
-    if (!attr_done) { (void)set_max_dyn_smem((const void*)gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN, PIN>, Cfg::smem); attr_done = true; }
-    TRX_LAUNCH((gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN, PIN>), dim3(cdiv_i(n, Cfg::QBN), cdiv_i(m, Cfg::QBM), batch), dim3(64 * Cfg::NW), Cfg::smem, s, m, n, k, alpha,
+    static std::once_flag attr_once;     // > 64 KB of dynamic LDS: opt in once per instantiation (host threads may race here)
+    std::call_once(attr_once, [] { (void)set_max_dyn_smem((const void*)gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>, Cfg::smem); });
+    TRX_LAUNCH((gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>), dim3(cdiv_i(n, Cfg::QBN), cdiv_i(m, Cfg::QBM), batch), dim3(64 * Cfg::NW), Cfg::smem, s, m, n, k, alpha,
                A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
 
+// 128 x 96 block tile: 4 x 2 waves of 2 x 3 MFMA tiles (two waves per SIMD: the partner wave covers load issue, barrier skew and LDS latency)
 template <int OPA, int OPB>
-int launch_big_cfg(hipStream_t s, int cfg, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
+int launch_big_cfg(hipStream_t s, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
                    long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
-    switch (cfg) {
-        // one wave per SIMD, accumulators pinned to AGPRs
-        case 1: return launch_big<OPA, OPB, 2, 2, 3, 3, true>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);     //  96 x 96
-        case 2: return launch_big<OPA, OPB, 4, 1, 2, 5, true>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);     // 128 x 80
-        // two waves per SIMD (8-wave workgroup), accumulators in VGPRs: the partner wave covers load issue, barrier skew and LDS latency
-        case 3: return launch_big<OPA, OPB, 4, 2, 2, 3, false>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);    // 128 x 96
-        default: return TRX_ERR_ARG;
-    }
+    return launch_big<OPA, OPB, 4, 2, 2, 3>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
 }
 
 template <int OPA>
-int launch_big_b(hipStream_t s, int cfg, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
+int launch_big_b(hipStream_t s, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb,
                  long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
     switch (opB) {
-        case TRX_OP_N: return launch_big_cfg<OPA, TRX_OP_N>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
-        case TRX_OP_T: return launch_big_cfg<OPA, TRX_OP_T>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
-        case TRX_OP_C: return launch_big_cfg<OPA, TRX_OP_C>(s, cfg, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_N: return launch_big_cfg<OPA, TRX_OP_N>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_T: return launch_big_cfg<OPA, TRX_OP_T>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_C: return launch_big_cfg<OPA, TRX_OP_C>(s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
         default: return TRX_ERR_ARG;
     }
 }
 }  // namespace
 
-void gemm_big_tile(int cfg, int* bm, int* bn) {
-    static const int t[4][2] = {{0, 0}, {96, 96}, {128, 80}, {128, 96}};
-    *bm = t[cfg][0]; *bn = t[cfg][1];
-}
+void gemm_big_tile(int* bm, int* bn) { *bm = 128; *bn = 96; }
 
-// The large-tile kernel (tile configuration cfg = 1 .. 3) on the whole m x n output (ragged edges by clamped loads and guarded stores).  The
+// The large-tile kernel on the whole m x n output (ragged edges by clamped loads and guarded stores).  The
 // caller (gemm.hip) decides when it pays and peels thin remainders off for the narrow tiles.
-int gemm_big(hipStream_t s, int cfg, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
+int gemm_big(hipStream_t s, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
              int ldb, long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
     switch (opA) {
-        case TRX_OP_N: return launch_big_b<TRX_OP_N>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
-        case TRX_OP_T: return launch_big_b<TRX_OP_T>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
-        case TRX_OP_C: return launch_big_b<TRX_OP_C>(s, cfg, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_N: return launch_big_b<TRX_OP_N>(s, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_T: return launch_big_b<TRX_OP_T>(s, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
+        case TRX_OP_C: return launch_big_b<TRX_OP_C>(s, opB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, b_upper);
         default: return TRX_ERR_ARG;
     }
 }

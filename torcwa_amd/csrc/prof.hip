@@ -86,7 +86,7 @@ extern "C" int trx_prof_reset(void) {
         TagData& t = g_tags[i];
         t.used = 0;
         t.open = 0;
-        t.stride = (i == PROF_QR_WINDOW || i == PROF_QR_APPLY_RIGHT) ? 16 : 1;
+        t.stride = (i == PROF_QR_WINDOW || i == PROF_QR_APPLY_LEFT) ? 16 : 1;
         t.launches = t.flops = t.bytes = 0;
     }
     return TRX_OK;
@@ -110,8 +110,8 @@ extern "C" int trx_prof_get(int tag, double* out) {
 }
 
 extern "C" const char* trx_prof_tag_name(int tag) {
-    static const char* names[PROF_NTAGS] = {"gemm<N,N>", "gemm<other ops>", "qr_prepare_kernel", "apply_window_kernel",
-                                            "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel", "invit_solve_kernel",
+    static const char* names[PROF_NTAGS] = {"gemm<N,N>", "gemm<other ops>", "qr_prepare_kernel", "apply_links_kernel<1>",
+                                            "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel", "apply_links_kernel<0>",
                                             "gemm<N,N> fp32", "gemm<other ops> fp32"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }

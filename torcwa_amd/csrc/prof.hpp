@@ -6,7 +6,7 @@
 
 namespace trx {
 enum ProfTag { PROF_GEMM_NN = 0, PROF_GEMM_OTHER = 1, PROF_QR_PREPARE = 2, PROF_QR_APPLY_RIGHT = 3, PROF_QR_WINDOW = 4,
-               PROF_HESS_GEMV = 5, PROF_HESS_COL = 6, PROF_LU_PANEL = 7, PROF_INVIT = 8, PROF_GEMM_NN_F32 = 9, PROF_GEMM_OTHER_F32 = 10, PROF_NTAGS = 11 };      // the fp32 GEMMs (first stage of the
+               PROF_HESS_GEMV = 5, PROF_HESS_COL = 6, PROF_LU_PANEL = 7, PROF_QR_APPLY_LEFT = 8, PROF_GEMM_NN_F32 = 9, PROF_GEMM_OTHER_F32 = 10, PROF_NTAGS = 11 };      // the fp32 GEMMs (first stage of the
                // mixed-precision eigensolver, precision="native") are counted apart from the fp64 ones: other peak, other roofline
 
 bool prof_enabled();
