@@ -163,6 +163,28 @@ def test_eig_deferred_right_update(backend, spw):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, qr_regs=3, slab_lds=54), dict(qr_super=1), dict(qr_super=3, slab_band=1, qr_regs=1)])
+def test_eig_super_steps_fp32(backend, knobs):
+    """fp32 QR phase (first stage of the mixed-precision route; complex64 problems under precision="native"): a launch of the window kernel
+    takes the chain through up to 8 windows, applying each window's unitary itself to the band of columns the following windows slide
+    over; the left update beyond the band is one launch per super-step over its links, the right / Z update one launch per sweep.  Sizes
+    with several super-steps per sweep; a spread spectrum (early deflations move the active block) next to a dense matrix.  The lean
+    (64 / 128 register) builds of the kernels and the LDS reserve of the update workgroups select code, not results."""
+    if backend == "emu" and knobs != dict(qr_super=4):
+        pytest.skip("emulator time budget: the default super-step length only")
+    be = get_backend(backend)
+    n = 200 if backend == "emu" else 450
+    A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex64)
+    A[1] = (0.3 * A[1] + np.diag(np.linspace(-12, 12, n))).astype(np.complex64)
+    try:
+        _set_knobs(be, **knobs)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, **{k: 0 for k in knobs})
+    check(A, w, V, info, 5e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("chains", [3, 2, 1])
 def test_eig_multiple_bulge_chains(backend, chains):
     """Active blocks long enough for three bulge chains per sweep (chain c follows chain c-1 one window behind; 48 of the AED

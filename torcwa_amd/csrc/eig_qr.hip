@@ -575,227 +575,6 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
 }
 
-// Window of a chain whose chase step is tau: starts one row above its last bulge (clamped to the active block), QW wide.
-__device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, int tau_last, int& w0, int& w1, int& tau_end) {
-    w0 = ilo + tau - 2 * (k - 1) - 1;
-    if (w0 < ilo) w0 = ilo;
-    w1 = w0 + QW;
-    if (w1 > ihi + 1) w1 = ihi + 1;
-    tau_end = (w1 == ihi + 1) ? tau_last : (w1 - 3 - ilo);
-}
-
-// One window step of one bulge chain (blockIdx.x = chain, blockIdx.y = matrix).  Thread layout: QNS groups of LPB lanes, group s owns bulge s: its lanes compute the
-// rotation redundantly (no broadcast barrier), then stride over the window's columns (left rotation) and, after one barrier,
-// over its rows and the rows of U (right rotation).  Two barriers per chain step.  LPB = 64 (one wave per bulge, 1024
-// threads): a chain step is bound by the fp64 vector issue time of the 2 + 4 rotated element pairs per lane-quartet (cycle
-// counters, TRX_QR_DEBUG: 16 lanes per bulge spent 3600 cycles per step, ~2600 of them in the two rotation phases), so the
-// widest mapping the 64-wide window admits is the fastest one.
-// Two phases in ONE window-sized LDS buffer: (1) the chase on the H window, every rotation logged (c, s: 24 bytes); H written
-// back; (2) the same buffer becomes U = I and the log is replayed onto it (bulge s's wave rotates its two columns, one barrier
-// per chain step).  With H and U side by side the kernel needed 133 KB of LDS; now 66.5 KB + the log.  (The hope that a smaller
-// footprint would let window launches start next to the slab-update workgroups of the other iteration groups did not
-// materialise: a slab launch occupies every workgroup slot of the chip whatever is left of a CU's LDS -- DESIGN.md section 9.)
-constexpr int LPB = 64;                    // lanes per bulge
-constexpr int WTHREADS = QNS * LPB;        // threads of the window kernel
-constexpr int WIT = QW / LPB;              // element pairs per lane and phase
-constexpr int WMAXS = 96;                  // chain steps per launch (rotation log: WMAXS x QNS entries = 37 KB): the first window of a sweep
-                                           // chases 62 steps and the last one up to ~94, so no launch is split (48 split 7 % of them)
-template <class T> struct RotCS { T c; cx<T> s; };
-// DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it (it must stay within
-// 64 VGPRs: 4 of its waves share a SIMD's 512 registers with one 240-register wave of a slab-update workgroup).
-template <class T, bool DBG>
-__global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
-                                                        cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
-                                                        int par, int nslot, int kc, int q, long long* dbg_all = nullptr) {
-    TRX_DYN_SMEM(smem);
-    long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
-    long long tk0 = dbg ? clock64() : 0;
-    constexpr int LD = QW + 1;
-    cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
-    RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
-    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
-    const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
-    if (t == 0) sst = st_all[b];
-    __syncthreads();
-    // this step's entry of the link log: EVERY exit path writes it (the update kernels walk over all slots of the sweep)
-    QrLink* link = links_all + ((long)b * nslot + q) * kc + ch;
-    const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
-    // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
-    // positions go to the [par] copy, which nobody writes in this step.
-    if (st.mode == QR_SMALL_PENDING || st.mode == QR_AED_CHASE) {
-        // this slot applies the unitary of the finished block / the AED window (written by the prepare kernel): a dense link, updated on all sides at once
-        if (t == 0) {
-            QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
-            if (ch == 0) { l.w0 = st.w0[0]; l.w1 = st.w1[0]; l.kind = QRL_DENSE; l.e = l.w1; st_all[b].mode = st.mode == QR_SMALL_PENDING ? QR_SMALL_APPLIED : QR_CHASE; }
-            *link = l;
-        }
-        return;
-    }
-    const int tau0 = st.tau[ch][par];
-    bool move = (st.mode == QR_CHASE) && ch < st.nch && tau0 <= st.tau_last[ch];
-    const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi;
-    int w0 = 0, w1 = 0, tau_end = 0;
-    if (move) {
-        chain_window(ilo, ihi, k, tau0, st.tau_last[ch], w0, w1, tau_end);
-        if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several launches
-        if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
-            // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
-            // this step); this chain may only work strictly above it
-            int p0, p1, pe;
-            chain_window(ilo, ihi, st.k[ch - 1], st.tau[ch - 1][par], st.tau_last[ch - 1], p0, p1, pe);
-            if (w1 > p0) move = false;
-        }
-    }
-    if (!move) {
-        if (t == 0) {
-            QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
-            *link = l;
-            st_all[b].tau[ch][par ^ 1] = tau0;
-        }
-        return;
-    }
-    cx<T>* H = Aall + (long)b * mstride;
-    const int ww = w1 - w0;
-    {
-        // window load: QW*QW/WTHREADS independent (clamped) global loads per thread in flight, then the LDS fill
-        constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;      // rows per thread, row stride between them
-        const int c = t & (QW - 1), r4 = t / QW;
-        const int cc = c < ww ? c : ww - 1;
-        cx<T> hv[RPT];
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = r4 + RSTEP * i;
-            hv[i] = H[(long)(w0 + (r < ww ? r : ww - 1)) * n + w0 + cc];
-        }
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = r4 + RSTEP * i;
-            if (r < ww && c < ww) Hw[r * LD + c] = hv[i];
-        }
-    }
-    const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
-    const cx<T> shift = (sb < k) ? shifts_all[((long)b * QKC + ch) * QNS + sb] : cx<T>(T(0), T(0));
-    __syncthreads();
-    if (dbg) { const long long t1 = clock64(); dbg[12] += t1 - tk0; tk0 = t1; }
-    // Every phase of a chain step touches WIT element pairs per lane: the loops are fully unrolled with clamped LDS reads issued
-    // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
-    // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
-    // barrier absorbs the skew.)
-    for (int tau = tau0; tau <= tau_end; ++tau) {
-        const int p = ilo + tau - 2 * sb;
-        const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
-        const int q = p - w0;
-        const bool first = (p == ilo);
-        Rot<T> R;
-        if (active) {
-            cx<T> f, g;
-            if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
-            else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
-            R = rotg_fast(f, g);
-        } else { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0)); }
-        if (j == 0) { rlog[(tau - tau0) * QNS + sb].c = R.c; rlog[(tau - tau0) * QNS + sb].s = R.s; }
-        wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
-        if (dbg) { const long long t1 = clock64(); dbg[16] += t1 - tk0; tk0 = t1; }
-        if (active) {
-            const int lo = first ? q : q - 1;
-            cx<T> x[WIT], y[WIT];
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int col = lo + j + LPB * it;
-                const int cl = col < ww ? col : ww - 1;
-                x[it] = Hw[q * LD + cl]; y[it] = Hw[(q + 1) * LD + cl];
-            }
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int col = lo + j + LPB * it;
-                rot_rows(R, x[it], y[it]);
-                if (!first && col == q - 1) { x[it] = R.r; y[it] = cx<T>(T(0), T(0)); }
-                if (col < ww) { Hw[q * LD + col] = x[it]; Hw[(q + 1) * LD + col] = y[it]; }
-            }
-        }
-        if (dbg) { const long long t1 = clock64(); dbg[17] += t1 - tk0; tk0 = t1; }
-        __syncthreads();
-        if (dbg) { const long long t1 = clock64(); dbg[18] += t1 - tk0; tk0 = t1; }
-        if (active) {
-            const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
-            cx<T> xh[WIT], yh[WIT];
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int row = j + LPB * it;
-                const int rh = row <= hi ? row : hi;
-                xh[it] = Hw[rh * LD + q]; yh[it] = Hw[rh * LD + q + 1];
-            }
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int row = j + LPB * it;
-                rot_cols(R, xh[it], yh[it]);
-                if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
-            }
-        }
-        if (dbg) { const long long t1 = clock64(); dbg[19] += t1 - tk0; tk0 = t1; }
-        __syncthreads();
-        if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
-    }
-    if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
-    cx<T>* U = Ulog_all + (((long)b * nslot + q) * kc + ch) * QW * QW;
-    constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;
-    {
-        // phase 1 done: the window goes back to H, the buffer becomes U = I
-        const int c = t & (QW - 1), r4 = t / QW;
-        cx<T> hv[RPT];
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = r4 + RSTEP * i;
-            if (r < ww && c < ww) H[(long)(w0 + r) * n + w0 + c] = hv[i];
-            Hw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
-        }
-    }
-    __syncthreads();
-    // phase 2: replay the logged rotations onto U (right multiplications; within a chain step the bulges own disjoint column pairs)
-    for (int tau = tau0; tau <= tau_end; ++tau) {
-        const int p = ilo + tau - 2 * sb;
-        const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
-        if (active) {
-            const int q = p - w0;
-            Rot<T> R;
-            R.c = rlog[(tau - tau0) * QNS + sb].c; R.s = rlog[(tau - tau0) * QNS + sb].s;
-            cx<T> xu[WIT], yu[WIT];
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int row = j + LPB * it;
-                const int ru = row < ww ? row : ww - 1;
-                xu[it] = Hw[ru * LD + q]; yu[it] = Hw[ru * LD + q + 1];
-            }
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int row = j + LPB * it;
-                rot_cols(R, xu[it], yu[it]);
-                if (row < ww) { Hw[row * LD + q] = xu[it]; Hw[row * LD + q + 1] = yu[it]; }
-            }
-        }
-        __syncthreads();
-    }
-    {
-        const int c = t & (QW - 1), r4 = t / QW;
-        if (c < ww) {
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int r = r4 + RSTEP * i;
-                if (r < ww) U[r * QW + c] = Hw[r * LD + c];
-            }
-        }
-    }
-    if (t == 0) {
-        st_all[b].tau[ch][par ^ 1] = tau_end + 1;
-        QrLink l; l.w0 = w0; l.w1 = w1; l.kind = QRL_CHASE; l.e = w1;
-        *link = l;
-    }
-    if (dbg) dbg[14] += clock64() - tk0;
-}
-
 // Off-window updates on the matrix cores: H[w0:w1, w1:n) <- U^H H[w0:w1, w1:n)   (left),  H[0:w0, w0:w1) <- H[0:w0, w0:w1) U  and
 // Z[:, w0:w1) <- Z[:, w0:w1) U   (right), with the window unitary U (ww x ww, ww <= 64) of a link of the log.
 //
@@ -807,7 +586,9 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
 // a lane of the right update reads 4 consecutive elements of its row; both operands use the same permutation.
 // Algorithmic intensity: 8*16*64*64 flops per 2*16 KiB moved = 16 flop/B in fp64 (32 in fp32); the deferred right update re-reads, per link,
 // a block whose left 33 columns it wrote itself one link earlier (L2-hot), so about half of that traffic reaches HBM.
-constexpr int MLD = 72;           // LDS plane row stride: element U[k][c] at [k*MLD + c]
+constexpr int MLD = 68;           // LDS plane row stride: element U[k][c] at [k*MLD + c].  The k-groups of a fragment read are 4 rows apart (kstep below):
+                                  // 4 * 68 = 272 elements = 16 banks (fp32, ds_read_b32: 32 banks) / 32 banks (fp64, ds_read_b64: 64 banks) -- no two
+                                  // of the 32 lanes an LDS cycle serves share a bank (72 put every k-group on the same banks: 2-way conflicts)
 // k index a lane of k-group lk (= lane >> 4) supplies at MFMA step (h, cc, j): k = kstep(h, cc, j) + KLS * lk.  Permuted order
 // (16 c + 4 lk + j): the four loads (j) of a lane of the right update are 64 contiguous bytes.  The natural order 4 step + lk
 // (the four k-groups of ONE instruction contiguous instead) was measured too: 28.0 vs 28.4 solves/s, so the permutation stays.
@@ -845,46 +626,50 @@ __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int
         }
 }
 
-// BAND (see slab_multiply_half_3m): output tile q skips the k chunks c >= q + 2 of a chase unitary (compile-time conditions: h, cc, q are
-// unrolled constants)
+// 4M product of one K half for the tile pair (2 pp, 2 pp + 1).  BAND (see slab_multiply_half_3m): output tile q skips the k chunks
+// c >= q + 2 of a chase unitary (compile-time conditions: h, cc, pp are unrolled constants).
 template <class T, int SIDE, bool BAND = false>
-__device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int lane, const cx<T> (&x)[8],
-                                                   typename Mfma<T>::acc_t (&accR)[4], typename Mfma<T>::acc_t (&accI)[4]) {
+__device__ __forceinline__ void slab_multiply_half_pair(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int pp, int lane, const cx<T> (&x)[8],
+                                                        typename Mfma<T>::acc_t (&accR)[2], typename Mfma<T>::acc_t (&accI)[2]) {
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int chunk = 2 * h + cc;
-            const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr;
+            const bool use0 = !(BAND && chunk >= 2 * pp + 2), use1 = !(BAND && chunk >= 2 * pp + 3);       // tiles 2pp, 2pp + 1
+            if (!use0 && !use1) continue;
+            const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr + 32 * pp;
             const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
-            T ur[4], ui[4];
+            T ur[2], ui[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (BAND && chunk >= q + 2) continue;
+            for (int q = 0; q < 2; ++q) {
+                if (!(q == 0 ? use0 : use1)) continue;
                 ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
             }
             if (SIDE == 1) {          // C = X U:      Cr += xr ur - xi ui,  Ci += xr ui + xi ur          (A = x, B = u)
                 const T nxi = -xi;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(xr, ur[q], accR[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accR[q] = Mfma<T>::mma(xr, ur[q], accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xr, ui[q], accI[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accI[q] = Mfma<T>::mma(xr, ui[q], accI[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(nxi, ui[q], accR[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accR[q] = Mfma<T>::mma(nxi, ui[q], accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xi, ur[q], accI[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accI[q] = Mfma<T>::mma(xi, ur[q], accI[q]);
             } else {                  // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr          (A = conj(u)^T, B = x)
                 const T nxr = -xr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ur[q], xr, accR[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accR[q] = Mfma<T>::mma(ur[q], xr, accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ur[q], xi, accI[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accI[q] = Mfma<T>::mma(ur[q], xi, accI[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ui[q], xi, accR[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accR[q] = Mfma<T>::mma(ui[q], xi, accR[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
+                for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
             }
+            // bound the hoisting of the U fragment reads to the next two k-steps (register budget)
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
@@ -1009,39 +794,355 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
         }
         return;
     }
-    typename Mfma<T>::acc_t accR[4], accI[4];
+    // fp32: 4M product (its error budget is the tight one), two of the four output tiles at a time: 16 accumulator registers, so that the
+    // kernel fits 128 registers and two of its workgroups share a CU with a window workgroup
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int pp = 0; pp < 2; ++pp) {
+        typename Mfma<T>::acc_t accR[2], accI[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { accR[q][r] = T(0); accI[q][r] = T(0); }
-    slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 0, lane, xa, accR, accI);
-    slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 1, lane, xb, accR, accI);
-    slab_store<T>(d, n, w0, ww, lane, accR, accI);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accR[q][r] = T(0); accI[q][r] = T(0); }
+        slab_multiply_half_pair<T, SIDE, BAND>(Ur, Ui, 0, pp, lane, xa, accR, accI);
+        slab_multiply_half_pair<T, SIDE, BAND>(Ur, Ui, 1, pp, lane, xb, accR, accI);
+        slab_store_pair<T>(d, n, w0, ww, lane, pp, accR, accI);
+    }
 }
 
-// Result register r of tile q:  right update: strip row crow(lane, r), window column 16q + (lane&15);
-//                               left update:  window row 16q + crow(lane, r), strip column lane&15.
+// Window of a chain whose chase step is tau: starts one row above its last bulge (clamped to the active block), QW wide.
+__device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, int tau_last, int& w0, int& w1, int& tau_end) {
+    w0 = ilo + tau - 2 * (k - 1) - 1;
+    if (w0 < ilo) w0 = ilo;
+    w1 = w0 + QW;
+    if (w1 > ihi + 1) w1 = ihi + 1;
+    tau_end = (w1 == ihi + 1) ? tau_last : (w1 - 3 - ilo);
+}
+
+// Window steps of one bulge chain (blockIdx.x = chain, blockIdx.y = matrix).  Thread layout: QNS groups of LPB lanes, group s owns bulge s: its lanes compute the
+// rotation redundantly (no broadcast barrier), then stride over the window's columns (left rotation) and, after one barrier,
+// over its rows and the rows of U (right rotation).  Two barriers per chain step.  LPB = 64 (one wave per bulge, 1024
+// threads): a chain step is bound by the vector issue time of the 2 + 4 rotated element pairs per lane-quartet (cycle
+// counters, TRX_QR_DEBUG: 16 lanes per bulge spent 3600 cycles per step, ~2600 of them in the two rotation phases), so the
+// widest mapping the 64-wide window admits is the fastest one.
+// Two phases in ONE window-sized LDS buffer: (1) the chase on the H window, every rotation logged (c, s: 24 bytes); H written
+// back; (2) the same buffer becomes U = I and the log is replayed onto it (bulge s's wave rotates its two columns, one barrier
+// per chain step).
+//
+// SUPER-STEPS (one chain per sweep, fp32): a launch takes the chain through `nsteps` consecutive windows.  Window step s + 1 needs, of
+// everything off window s, only the NEW COLUMNS it slides over to have received U_s^H from the left -- so the workgroup applies U_s^H itself
+// to the band [w1_s, E) right of its window (E = end of the band all steps of the launch share, <= nsteps * 31 + ... columns; one 16-column
+// strip per wave on the matrix cores, U_s converted in place to the split re/im planes the strip code reads), publishes (w0, w1, E) in
+// the link and moves on; the left update of the columns from E on is ONE launch per super-step over all its links (apply_links_kernel<0>),
+// the right / Z update one launch per sweep.  A sweep over 1922 rows is then ~16 launches of each kind instead of 62 window -> update pairs.
+constexpr int LPB = 64;                    // lanes per bulge
+constexpr int WTHREADS = QNS * LPB;        // threads of the window kernel
+constexpr int WIT = QW / LPB;              // element pairs per lane and phase
+constexpr int WMAXS = 96;                  // chain steps per window (rotation log: WMAXS x QNS entries = 37 KB): the first window of a sweep
+                                           // chases 62 steps and the last one up to ~94, so no window is split (48 split 7 % of them)
+constexpr int QSUPER = 8;                  // most window steps per launch
+template <class T> struct RotCS { T c; cx<T> s; };
+
+// Left update of ONE 16-column strip of the band by one wave, lean in registers (the window kernel runs 4 waves per SIMD): the strip's
+// 64 x 16 block goes to registers in MFMA fragment layout (slab_load_half), then one 16 x 16 output tile at a time
+// (8 accumulator registers) with the banded structure of a chase unitary (tile q needs the k chunks <= q + 1 only).
 template <class T>
-__device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0, int ww, int lane, const typename Mfma<T>::acc_t (&accR)[4],
-                                           const typename Mfma<T>::acc_t (&accI)[4]) {
-    const int lr = lane & 15;
-    char* base = reinterpret_cast<char*>(d.X);       // scalar base + 32-bit byte offsets, as in slab_load_half
+__device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane, bool band) {
+    const int lr = lane & 15, lk = lane >> 4;
+    char* base = reinterpret_cast<char*>(d.X);
+    // x[4 c + j] <- H[w0 + k, a0 + lr], k = 16 c + 4 lk + j (clamped as in slab_load_half: beyond ww it meets zero rows of the planes).  One
+    // address register: the offset advances load by load (sched_barrier keeps address arithmetic and load together; the loads stay in flight)
+    cx<T> x[16];
+    {
+        const int a = d.a0 + lr;
+        const int ac = a < d.lim ? a : d.lim - 1;
+        const unsigned ks = (unsigned)n * (unsigned)sizeof(cx<T>);
+        const unsigned p0 = ((unsigned)w0 * n + ac) * (unsigned)sizeof(cx<T>);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int cr = Mfma<T>::crow(lane, r);
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const cx<T> v(accR[q][r], accI[q][r]);
-            if (d.side == 1) {
-                const int row = d.a0 + cr, k = 16 * q + lr;
-                if (row < d.lim && k < ww) *reinterpret_cast<cx<T>*>(base + ((unsigned)row * n + w0 + k) * (unsigned)sizeof(cx<T>)) = v;
-            } else {
-                const int i = 16 * q + cr, col = d.a0 + lr;
-                if (i < ww && col < d.lim) *reinterpret_cast<cx<T>*>(base + ((unsigned)(w0 + i) * n + col) * (unsigned)sizeof(cx<T>)) = v;
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * c + KLS * lk + j;
+                x[4 * c + j] = *reinterpret_cast<const cx<T>*>(base + (p0 + (unsigned)(k < ww ? k : ww - 1) * ks));
+                __builtin_amdgcn_sched_barrier(0);
             }
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        typename Mfma<T>::acc_t accR, accI;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); }
+        const int cmax = band ? q + 1 : 3;              // last k chunk with a nonzero block in tile column q
+        const T* ur = Ur + (KLS * lk) * MLD + lr + 16 * q;
+        const T* ui = Ui + (KLS * lk) * MLD + lr + 16 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > cmax) continue;                      // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T a = ur[(16 * c + j) * MLD], bq = ui[(16 * c + j) * MLD];
+                const cx<T> xv = x[4 * c + j];
+                // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr
+                accR = Mfma<T>::mma(a, xv.x, accR);
+                accI = Mfma<T>::mma(a, xv.y, accI);
+                accR = Mfma<T>::mma(bq, xv.y, accR);
+                accI = Mfma<T>::mma(bq, -xv.x, accI);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);        // bounds the hoisting of the fragment reads (register budget)
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * q + Mfma<T>::crow(lane, r), col = d.a0 + lr;
+            if (i < ww && col < d.lim) *reinterpret_cast<cx<T>*>(base + ((unsigned)(w0 + i) * n + col) * (unsigned)sizeof(cx<T>)) = cx<T>(accR[r], accI[r]);
         }
     }
 }
+
+// waves per SIMD the window kernel is compiled for: LEAN (fp32) 8, i.e. <= 64 registers, so that it fits next to update workgroups (knob qr_regs)
+#define WINDOW_MIN_WG(T, LEAN) ((sizeof(T) == 4 && LEAN) ? 8 : 1)
+// DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it (it must stay within
+// 64 VGPRs: 4 of its waves share a SIMD's 512 registers with the waves of the update workgroups).
+template <class T, bool DBG, bool LEAN = false>
+__global__ __launch_bounds__(WTHREADS, WINDOW_MIN_WG(T, LEAN)) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
+                                                        cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
+                                                        int par, int nslot, int kc, int slot0, int nsteps, int band_on, long long* dbg_all = nullptr) {
+    TRX_DYN_SMEM(smem);
+    long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
+    long long tk0 = dbg ? clock64() : 0;
+    constexpr int LD = QW + 1;
+    cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
+    RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
+    QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
+    int* sflag = reinterpret_cast<int*>(&sst + 1);                   // "U has a nonzero outside the band"
+    T* Ur = reinterpret_cast<T*>(smem);              // [QW][MLD] x 2: split planes of U for the band update, over Hw | rlog (both dead by then)
+    T* Ui = Ur + QW * MLD;
+    static_assert(sizeof(T) * 2 * QW * MLD <= sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS, "planes fit over window + log");
+    const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
+    if (t == 0) sst = st_all[b];
+    __syncthreads();
+    // the entries of the link log of these window steps: EVERY exit path writes them (the update kernels walk over all slots of the sweep)
+    QrLink* links = links_all + ((long)b * nslot + slot0) * kc + ch;         // step s: links[s * kc]
+    const QrState& st = sst;           // read in place (LDS): a register copy indexed by the chain number would live in scratch
+    // Every block writes only the fields of its own chain (and chain 0's block the mode); reads of the other chains' chase
+    // positions go to the [par] copy, which nobody writes in this launch (several chains: one window step per launch).
+    if (st.mode == QR_SMALL_PENDING || st.mode == QR_AED_CHASE) {
+        // this slot applies the unitary of the finished block / the AED window (written by the prepare kernel): a dense link, updated on all sides at once
+        if (t == 0) {
+            QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
+            for (int s = 1; s < nsteps; ++s) links[s * kc] = l;
+            if (ch == 0) { l.w0 = st.w0[0]; l.w1 = st.w1[0]; l.kind = QRL_DENSE; l.e = l.w1; st_all[b].mode = st.mode == QR_SMALL_PENDING ? QR_SMALL_APPLIED : QR_CHASE; }
+            links[0] = l;
+        }
+        return;
+    }
+    const int k = st.k[ch], ilo = st.ilo, ihi = st.ihi, tau_last = st.tau_last[ch];
+    const bool chasing = (st.mode == QR_CHASE) && ch < st.nch;
+    int tau_cur = st.tau[ch][par];
+    int band_e = 0;                                  // end of the band this launch keeps up to date itself (0: not decided yet)
+    cx<T>* H = Aall + (long)b * mstride;
+    const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
+    const cx<T> shift = (sb < k) ? shifts_all[((long)b * QKC + ch) * QNS + sb] : cx<T>(T(0), T(0));
+    constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;      // window elements per thread, row stride between them
+    for (int s = 0; s < nsteps; ++s) {
+        const int tau0 = tau_cur;
+        bool move = chasing && tau0 <= tau_last;
+        int w0 = 0, w1 = 0, tau_end = 0;
+        if (move) {
+            chain_window(ilo, ihi, k, tau0, tau_last, w0, w1, tau_end);
+            if (tau_end > tau0 + WMAXS - 1) tau_end = tau0 + WMAXS - 1;      // first and last window of a sweep: several steps
+            if (ch > 0 && st.tau[ch - 1][par] <= st.tau_last[ch - 1]) {
+                // the chain ahead is still under way: its last bulge sits at the start of ITS window (whether or not it moves in
+                // this step); this chain may only work strictly above it
+                int p0, p1, pe;
+                chain_window(ilo, ihi, st.k[ch - 1], st.tau[ch - 1][par], st.tau_last[ch - 1], p0, p1, pe);
+                if (w1 > p0) move = false;
+            }
+        }
+        if (!move) {
+            if (t == 0) {
+                QrLink l; l.w0 = 0; l.w1 = 0; l.kind = QRL_NONE; l.e = 0;
+                for (int s2 = s; s2 < nsteps; ++s2) links[s2 * kc] = l;
+            }
+            break;
+        }
+        const int ww = w1 - w0;
+        if (band_e == 0) {
+            // in-kernel band: fp32, one chain per sweep.  Every window of this launch ends at most (QW - 2 k - 1) columns further right
+            // than the one before, and the first window of the NEXT launch as well: all of them lie left of E.
+            band_e = w1;
+            if constexpr (sizeof(T) == 4) { if (kc == 1 && band_on) { band_e = w1 + nsteps * (QW - 2 * k - 1); if (band_e > n) band_e = n; } }
+        }
+        {
+            // window load: QW*QW/WTHREADS independent (clamped) global loads per thread in flight, then the LDS fill
+            const int c = t & (QW - 1), r4 = t / QW;
+            const int cc = c < ww ? c : ww - 1;
+            cx<T> hv[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = r4 + RSTEP * i;
+                hv[i] = H[(long)(w0 + (r < ww ? r : ww - 1)) * n + w0 + cc];
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = r4 + RSTEP * i;
+                if (r < ww && c < ww) Hw[r * LD + c] = hv[i];
+            }
+        }
+        __syncthreads();
+        if (dbg) { const long long t1 = clock64(); dbg[12] += t1 - tk0; tk0 = t1; }
+        // Every phase of a chain step touches WIT element pairs per lane: the loops are fully unrolled with clamped LDS reads issued
+        // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
+        // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
+        // barrier absorbs the skew.)
+        for (int tau = tau0; tau <= tau_end; ++tau) {
+            const int p = ilo + tau - 2 * sb;
+            const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
+            const int q = p - w0;
+            const bool first = (p == ilo);
+            Rot<T> R;
+            if (active) {
+                cx<T> f, g;
+                if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
+                else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
+                R = rotg_fast(f, g);
+            } else { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0)); }
+            if (j == 0) { rlog[(tau - tau0) * QNS + sb].c = R.c; rlog[(tau - tau0) * QNS + sb].s = R.s; }
+            wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
+            if (dbg) { const long long t1 = clock64(); dbg[16] += t1 - tk0; tk0 = t1; }
+            if (active) {
+                const int lo = first ? q : q - 1;
+                cx<T> x[WIT], y[WIT];
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int col = lo + j + LPB * it;
+                    const int cl = col < ww ? col : ww - 1;
+                    x[it] = Hw[q * LD + cl]; y[it] = Hw[(q + 1) * LD + cl];
+                }
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int col = lo + j + LPB * it;
+                    rot_rows(R, x[it], y[it]);
+                    if (!first && col == q - 1) { x[it] = R.r; y[it] = cx<T>(T(0), T(0)); }
+                    if (col < ww) { Hw[q * LD + col] = x[it]; Hw[(q + 1) * LD + col] = y[it]; }
+                }
+            }
+            if (dbg) { const long long t1 = clock64(); dbg[17] += t1 - tk0; tk0 = t1; }
+            __syncthreads();
+            if (dbg) { const long long t1 = clock64(); dbg[18] += t1 - tk0; tk0 = t1; }
+            if (active) {
+                const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
+                cx<T> xh[WIT], yh[WIT];
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    const int rh = row <= hi ? row : hi;
+                    xh[it] = Hw[rh * LD + q]; yh[it] = Hw[rh * LD + q + 1];
+                }
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    rot_cols(R, xh[it], yh[it]);
+                    if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
+                }
+            }
+            if (dbg) { const long long t1 = clock64(); dbg[19] += t1 - tk0; tk0 = t1; }
+            __syncthreads();
+            if (dbg) { const long long t1 = clock64(); dbg[20] += t1 - tk0; tk0 = t1; }
+        }
+        if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
+        cx<T>* U = Ulog_all + (((long)b * nslot + slot0 + s) * kc + ch) * QW * QW;
+        {
+            // phase 1 done: the window goes back to H, the buffer becomes U = I
+            const int c = t & (QW - 1), r4 = t / QW;
+            cx<T> hv[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = r4 + RSTEP * i;
+                if (r < ww && c < ww) H[(long)(w0 + r) * n + w0 + c] = hv[i];
+                Hw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
+            }
+        }
+        __syncthreads();
+        // phase 2: replay the logged rotations onto U (right multiplications; within a chain step the bulges own disjoint column pairs)
+        for (int tau = tau0; tau <= tau_end; ++tau) {
+            const int p = ilo + tau - 2 * sb;
+            const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
+            if (active) {
+                const int q = p - w0;
+                Rot<T> R;
+                R.c = rlog[(tau - tau0) * QNS + sb].c; R.s = rlog[(tau - tau0) * QNS + sb].s;
+                cx<T> xu[WIT], yu[WIT];
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    const int ru = row < ww ? row : ww - 1;
+                    xu[it] = Hw[ru * LD + q]; yu[it] = Hw[ru * LD + q + 1];
+                }
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    rot_cols(R, xu[it], yu[it]);
+                    if (row < ww) { Hw[row * LD + q] = xu[it]; Hw[row * LD + q + 1] = yu[it]; }
+                }
+            }
+            __syncthreads();
+        }
+        const bool do_band = sizeof(T) == 4 && band_e > w1;            // (workgroup-uniform; constant false in fp64)
+        {
+            // U goes to the log; for the band update also, through registers, into split planes over the same LDS (zero outside ww x ww)
+            const int c = t & (QW - 1), r4 = t / QW;
+            cx<T> hv[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
+            if (c < ww) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = r4 + RSTEP * i;
+                    if (r < ww) U[r * QW + c] = hv[i];
+                }
+            }
+            if constexpr (sizeof(T) == 4) if (do_band) {
+                if (t == 0) *sflag = 0;
+                __syncthreads();                         // every thread holds its part of U; the buffer may be overwritten
+                int dense = 0;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = r4 + RSTEP * i;
+                    cx<T> v = hv[i];
+                    if (r >= ww || c >= ww) v = cx<T>(T(0), T(0));
+                    Ur[r * MLD + c] = v.x; Ui[r * MLD + c] = v.y;
+                    if ((r >> 4) >= (c >> 4) + 2 && (v.x != T(0) || v.y != T(0))) dense = 1;
+                }
+                if (dense) *sflag = 1;
+                __syncthreads();
+            }
+        }
+        if (t == 0) {
+            QrLink l; l.w0 = w0; l.w1 = w1; l.kind = QRL_CHASE; l.e = band_e;
+            links[s * kc] = l;
+        }
+        if constexpr (sizeof(T) == 4) if (do_band) {
+            // left update of the band [w1, band_e): one 16-column strip per wave (16 waves)
+            const bool band = *sflag == 0;
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+            for (int a0 = w1 + 16 * wv; a0 < band_e; a0 += 16 * (WTHREADS / 64)) {
+                SlabStrip<T> d;
+                d.X = H; d.side = 0; d.a0 = a0; d.lim = band_e;
+                band_left_strip<T>(Ur, Ui, d, n, w0, ww, t & 63, band);
+            }
+        }
+        tau_cur = tau_end + 1;
+        if (dbg) { dbg[14] += clock64() - tk0; tk0 = clock64(); }
+        if (s + 1 < nsteps) __syncthreads();         // window write-back + band update visible to the next step's loads; LDS free again
+    }
+    if (t == 0) st_all[b].tau[ch][par ^ (nsteps & 1)] = tau_cur;
+}
+
+// Waves per SIMD the update kernel is compiled for: 2 (<= 256 registers); LEAN (fp32, knob qr_regs) 4, i.e. <= 128 registers: two of its workgroups
+// then leave half of a SIMD's registers to the 4 waves of a lean window workgroup.
+#define APPLY_MIN_WG(T, LEAN) ((sizeof(T) == 4 && LEAN) ? 4 : 2)
 
 // The update kernels walk over LINKS of the sweep's log (QrLink: window [w0, w1), kind, e = first column the left update still has to
 // reach; the window unitary sits in the same slot of the U log, that of a dense link in the per-matrix buffer the prepare kernel writes).
@@ -1059,8 +1160,8 @@ __device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0,
 //     on rows INSIDE a window, and no window of the sweep comes back to rows above an earlier one), and left / right multiplications
 //     commute, so the result is that of the interleaved order.  SEVERAL chains: a following chain's window does come back to rows the
 //     chain ahead has updated from the right, so the H part runs after every window step (nq = 1) and only Z waits for the end of the sweep.
-template <class T, int MODE>
-__global__ __launch_bounds__(256, 2) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+template <class T, int MODE, bool LEAN = false>
+__global__ __launch_bounds__(256, APPLY_MIN_WG(T, LEAN)) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                           const QrLink* __restrict__ links_all, const cx<T>* __restrict__ Ulog_all,
                                                           const cx<T>* __restrict__ Udense_all, unsigned* __restrict__ work, int nslot, int kc,
                                                           int q0, int nq, int spw, int units, int band_on) {
@@ -1068,6 +1169,7 @@ __global__ __launch_bounds__(256, 2) void apply_links_kernel(cx<T>* __restrict__
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
     int* wdense = reinterpret_cast<int*>(Ui + QW * MLD);          // [4] per-wave votes, behind the planes
+    QrLink* lks = reinterpret_cast<QrLink*>(wdense + 4);          // this launch's link records (one coalesced read instead of a dependent global read per link)
     const int b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
@@ -1078,10 +1180,12 @@ __global__ __launch_bounds__(256, 2) void apply_links_kernel(cx<T>* __restrict__
     const int row0 = MODE == 1 ? 64 * (isZ ? gx : gx - unitsZ) : 0;     // MODE 1: first of this workgroup's 64 rows
     cx<T>* H = Aall + (long)b * mstride;
     cx<T>* Z = Zall + (long)b * mstride;
+    for (int i = t; i < nq * kc; i += 256) lks[i] = links_all[((long)b * nslot + q0) * kc + i];
+    __syncthreads();
     bool staged = false;                                              // LDS holds a U some wave may still be reading
     for (int qq = q0; qq < q0 + nq; ++qq)
         for (int ch = (MODE == 0 ? ch0 : 0); ch < (MODE == 0 ? ch0 + 1 : kc); ++ch) {
-            const QrLink* lp = links_all + ((long)b * nslot + qq) * kc + ch;
+            const QrLink* lp = lks + (qq - q0) * kc + ch;
             const int kind = __builtin_amdgcn_readfirstlane(lp->kind);
             if (kind == QRL_NONE || (MODE == 1 && kind != QRL_CHASE)) continue;
             const int w0 = __builtin_amdgcn_readfirstlane(lp->w0), w1 = __builtin_amdgcn_readfirstlane(lp->w1);
@@ -1156,7 +1260,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, lds = 0, regs = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1177,6 +1281,9 @@ static QrKnobs& qr_knobs() {
         q.chains = geti("TRX_QR_CHAINS", 1, QKC, 0);
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
+        q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
+        q.lds = geti("TRX_SLAB_LDS", 1, 150, 0);              // KB of LDS an update workgroup reserves (caps the workgroups per CU chip-wide); 0 = automatic
+        q.regs = geti("TRX_QR_REGS", 0, 3, 0);                // bit 0: lean (64-register) fp32 window kernel, bit 1: lean (128-register) fp32 update kernels
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1233,6 +1340,9 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_rotb") { slot = &k.rotb; hi = 1; }
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
+    else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
+    else if (s == "slab_lds") { slot = &k.lds; hi = 150; }
+    else if (s == "qr_regs") { slot = &k.regs; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1244,8 +1354,17 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     constexpr int LD = QW + 1;
     if ((double)n * n * sizeof(cx<T>) >= 4294967296.0) return TRX_ERR_ARG;      // update kernels: 32-bit byte offsets inside one matrix
     const QrKnobs& K = qr_knobs();
-    const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState);
-    const size_t sma = sizeof(T) * 2 * QW * MLD + 16;        // + the four per-wave band votes
+    const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState) + 16;      // + the band flag
+    const int kc = qr_chains_for(batch);
+    const int nslot = qr_log_slots(n);
+    // update kernel: the two planes of U, the four per-wave band votes, the launch's link records -- and, in fp32, a RESERVE up to 54 KB:
+    // two update workgroups (108 KB) then leave room for the 52 KB of a window workgroup on every CU, and a third one does not fit,
+    // whichever iteration group it comes from -- the latency-bound window kernels of the other groups never wait for a CU.
+    size_t sma = sizeof(T) * 2 * QW * MLD + 16 + sizeof(QrLink) * (size_t)nslot * kc;
+    {
+        const size_t reserve = (size_t)(K.lds ? K.lds : (sizeof(T) == 4 ? 54 : 0)) * 1024;
+        if (sma < reserve) sma = reserve;
+    }
     auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
     // opt-in to > 64 KB of dynamic LDS: per (device, dtype), once; a failure is remembered so that no later call launches anyway
     static std::mutex attr_mu;
@@ -1256,8 +1375,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         std::lock_guard<std::mutex> lock(attr_mu);
         int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
         if (stt == 0) {
+            const size_t sma_max = 160 * 1024 - 512;     // (the reserve is a knob and the link records depend on n: opt in to the largest size once)
             const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) ||
-                  set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma) ||
+                  set_max_dyn_smem((const void*)qr_window_kernel<T, false, true>, smw) ||
+                  set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma_max) ||
+                  set_max_dyn_smem((const void*)apply_links_kernel<T, 0, true>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1, true>, sma_max) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
             stt = r ? 2 : 1;
         }
@@ -1276,9 +1398,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // batches; a single large matrix (the topology-optimisation case, n = 5202, batch 1) has no update work to protect and gains from the
     // shorter chain: 5.62 s (1 chain, AED 48) -> 5.16 s (3 chains) -> 4.79 s (3 chains, AED 64) for the whole forward solve
     // (profiles/r02_single_matrix_knobs.txt).
-    const int kc = qr_chains_for(batch);
-    const int nslot = qr_log_slots(n);
     const int band_on = K.band != 1;
+    // window steps per launch: the in-kernel band update exists in fp32 for one chain per sweep (the mixed-precision route's first stage)
+    const int super = (sizeof(T) == 4 && kc == 1) ? (K.super ? K.super : 4) : 1;
+    const bool lean_w = sizeof(T) == 4 && (K.regs & 1), lean_a = sizeof(T) == 4 && (K.regs & 2);
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1371,25 +1494,31 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int nwin = bound > 0 ? cdiv_i(bound + 2 * QNS, adv) + 2 + 4 * (kc - 1) : 1;
         if (nwin > nslot) nwin = nslot;
         unsigned* wk = (unsigned*)(G.summary + 3);
-        for (int q = 0; q < nwin; ++q) {
+        // slot 0 on its own: it may carry the dense link of an AED window / a finished block (all sides at once: up to 3 n / 16 + 3 strips),
+        // which must be applied before the chase starts; then super-steps of `super` window steps + ONE left update over their links
+        for (int q = 0; q < nwin;) {
+            const int ns = q == 0 ? 1 : (nwin - q < super ? nwin - q : super);
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, (long long*)nullptr); }
-            G.par ^= 1;
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, dbg_dev);
+              else if (lean_w) TRX_LAUNCH((qr_window_kernel<T, false, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, (long long*)nullptr);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, (long long*)nullptr); }
+            G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
-              // slot 0 may carry a dense link (left | right-H | Z: up to 3 n / 16 + 3 strips), the others only left updates (<= n / 16 + 1 strips)
               const int units = cdiv_i(q == 0 ? 3 * nstrip + 3 : nstrip + 1, 4 * spw);
-              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, 1, spw, units, band_on);
+              if (lean_a) TRX_LAUNCH((apply_links_kernel<T, 0, true>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
+              else TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed)
               if (kc > 1)
-                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, 1, 1, 1, band_on); }
+                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 1, band_on); }
+            q += ns;
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
         // deflation), so it cannot run beside it.
         { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
           const int parts = kc > 1 ? 2 : 3;
-          TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
+          if (lean_a) TRX_LAUNCH((apply_links_kernel<T, 1, true>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on);
+          else TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
         return true;
     };
     if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
