@@ -47,7 +47,7 @@ def by_grid(path, pattern, top=40):
         print(f"{k[0]:40s} {str(k[1:]):>20s} {a[0]:7d} {a[1] / 1e6:10.1f} {a[1] / a[0] / 1e3:10.1f} {100 * a[1] / tot:6.1f}%")
 
 
-PHASES = [("hessenberg", ("hess_", "pack_yv", "conj_transpose_panel", "set_identity")), ("qr", ("qr_prepare", "qr_window", "apply_window", "qr_init")),
+PHASES = [("hessenberg", ("hess_", "pack_yv", "conj_transpose_panel", "set_identity")), ("qr", ("qr_prepare", "qr_window", "apply_window", "apply_links", "qr_init")),
           ("schur_vectors", ("trevc", "colnorm"))]
 
 
@@ -130,7 +130,7 @@ def gaps(path, top=25, min_us=50.0, from_ms=0.0):
         print(f"{a[0]:7d} {a[1] / 1e6:9.1f}  {k[0]} -> {k[1]}")
 
 
-def concurrency(path, pattern="qr_|apply_window"):
+def concurrency(path, pattern="qr_|apply_window|apply_links"):
     """Time-weighted histogram of the number of kernels running at once while at least one kernel matching `pattern` runs, the
     same per stream/queue, and the in-stream gap between consecutive kernels of one stream (launch latency the GPU sees)."""
     con = sqlite3.connect(path)
@@ -192,7 +192,7 @@ def excerpt(path, at_frac=0.55, span_us=1500.0):
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     # start the excerpt at an apply_window kernel near at_frac
     lo = t0 + at_frac * (t1 - t0)
-    cand = [r for r in rows if r[0] >= lo and "apply_window" in r[2]]
+    cand = [r for r in rows if r[0] >= lo and ("apply_window" in r[2] or "apply_links" in r[2])]
     lo = cand[0][0] if cand else lo
     print(f"# timeline excerpt, {span_us:.0f} us from t = {(lo - t0) / 1e6:.1f} ms; columns: stream  start_us  dur_us  kernel  grid")
     for a, b, nm, sid, gx, gy in rows:
@@ -210,9 +210,12 @@ def lanes(path, at_frac=0.55, span_ms=30.0, bucket_us=100.0):
     rows = sorted((a, b, short(nm), sid) for nm, a, b, sid in con.cursor().execute(f"select name, start, end, {qcol} from kernels"))
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     lo = t0 + at_frac * (t1 - t0)
+    cand = [r for r in rows if r[0] >= lo and "qr_window" in r[2]]        # start inside a QR phase (a little after its beginning)
+    lo = cand[min(len(cand) - 1, 200)][0] if cand else lo
     hi = lo + span_ms * 1e6
     nb = int(span_ms * 1e3 / bucket_us)
-    kinds = (("qr_prepare", "P"), ("qr_window", "W"), ("apply_window", "A"), ("gemm", "G"), ("hess_", "H"), ("lu_", "L"), ("trsm", "L"))
+    kinds = (("qr_prepare", "P"), ("qr_window", "W"), ("apply_window", "A"), ("apply_links_f32_kernel<1", "R"), ("apply_links_kernel<float, 1", "R"), ("apply_links_kernel<double, 1", "R"),
+             ("apply_links", "A"), ("gemm", "G"), ("hess_", "H"), ("lu_", "L"), ("trsm", "L"))
     per = {}
     for a, b, nm, sid in rows:
         if b < lo or a > hi:

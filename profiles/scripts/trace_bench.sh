@@ -14,6 +14,7 @@ python $R/profiles/kernel_stats.py $DB --gaps-frac 0.55 > $R/gpurun_out/${TAG}_g
 python $R/profiles/kernel_stats.py $DB --concurrency > $R/gpurun_out/${TAG}_concurrency.txt 2>&1
 python $R/profiles/kernel_stats.py $DB --excerpt 0.55 > $R/gpurun_out/${TAG}_excerpt.txt 2>&1
 python $R/profiles/kernel_stats.py $DB --lanes 0.55 40 > $R/gpurun_out/${TAG}_lanes.txt 2>&1
+python $R/profiles/kernel_stats.py $DB --lanes 0.3 40 >> $R/gpurun_out/${TAG}_lanes.txt 2>&1
 python $R/profiles/kernel_stats.py $DB --by-grid gemm_mfma 40 > $R/gpurun_out/${TAG}_gemm_by_shape.txt
 CSV=$(find /tmp/tr_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$CSV" ] && head -45 $CSV > $R/gpurun_out/${TAG}_stats.csv

@@ -163,13 +163,12 @@ def test_eig_deferred_right_update(backend, spw):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, qr_regs=3, slab_lds=54), dict(qr_super=1), dict(qr_super=3, slab_band=1, qr_regs=1)])
+@pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, slab_spw=2), dict(qr_super=1), dict(qr_super=3, slab_band=1)])
 def test_eig_super_steps_fp32(backend, knobs):
     """fp32 QR phase (first stage of the mixed-precision route; complex64 problems under precision="native"): a launch of the window kernel
     takes the chain through up to 8 windows, applying each window's unitary itself to the band of columns the following windows slide
     over; the left update beyond the band is one launch per super-step over its links, the right / Z update one launch per sweep.  Sizes
-    with several super-steps per sweep; a spread spectrum (early deflations move the active block) next to a dense matrix.  The lean
-    (64 / 128 register) builds of the kernels and the LDS reserve of the update workgroups select code, not results."""
+    with several super-steps per sweep; a spread spectrum (early deflations move the active block) next to a dense matrix."""
     if backend == "emu" and knobs != dict(qr_super=4):
         pytest.skip("emulator time budget: the default super-step length only")
     be = get_backend(backend)

@@ -586,7 +586,10 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
 // a lane of the right update reads 4 consecutive elements of its row; both operands use the same permutation.
 // Algorithmic intensity: 8*16*64*64 flops per 2*16 KiB moved = 16 flop/B in fp64 (32 in fp32); the deferred right update re-reads, per link,
 // a block whose left 33 columns it wrote itself one link earlier (L2-hot), so about half of that traffic reaches HBM.
-constexpr int MLD = 68;           // LDS plane row stride: element U[k][c] at [k*MLD + c].  The k-groups of a fragment read are 4 rows apart (kstep below):
+#ifndef TRX_QR_VAR
+#define TRX_QR_VAR 0      // experiment switch of the fp32 update arithmetic (profiles/scripts/build_qr_variants.sh); 0 = the shipped code
+#endif
+constexpr int MLD = TRX_QR_VAR == 3 ? 72 : 68;           // LDS plane row stride: element U[k][c] at [k*MLD + c].  The k-groups of a fragment read are 4 rows apart (kstep below):
                                   // 4 * 68 = 272 elements = 16 banks (fp32, ds_read_b32: 32 banks) / 32 banks (fp64, ds_read_b64: 64 banks) -- no two
                                   // of the 32 lanes an LDS cycle serves share a bank (72 put every k-group on the same banks: 2-way conflicts)
 // k index a lane of k-group lk (= lane >> 4) supplies at MFMA step (h, cc, j): k = kstep(h, cc, j) + KLS * lk.  Permuted order
@@ -607,15 +610,16 @@ struct SlabStrip {       // wave-uniform description of one strip
 // used as is: for k >= ww it meets a zero row of the padded U in LDS, and a lane whose row / column lies outside the region
 // only feeds output elements that are never stored.  (No select after the load: the loaded registers have no consumer until
 // the MFMAs of the next strip, so the loads stay in flight behind the current strip's arithmetic.)
-template <class T>
+template <class T, int SIDE = -1>      // SIDE 0 / 1: compile-time side of the strip (no address arithmetic for the other one), -1: d.side
 __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int n, int w0, int ww, int lane, cx<T> (&x)[8]) {
+    const int side = SIDE >= 0 ? SIDE : d.side;
     const int lr = lane & 15, lk = lane >> 4;
     const int a = d.a0 + lr;
     const int ac = a < d.lim ? a : d.lim - 1;
     // 32-bit BYTE offsets from the wave-uniform matrix base (scalar base + 32-bit vector offset addressing; one address
     // register per access instead of two): requires n*n*sizeof(cx<T>) < 4 GiB, i.e. n < 16384 for complex128 (checked on the host)
-    const unsigned p0 = (d.side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>);
-    const unsigned ks = (d.side == 0 ? n : 1) * (unsigned)sizeof(cx<T>);
+    const unsigned p0 = (side == 0 ? (unsigned)w0 * n + ac : (unsigned)ac * n + w0) * (unsigned)sizeof(cx<T>);
+    const unsigned ks = (side == 0 ? n : 1) * (unsigned)sizeof(cx<T>);
     const char* base = reinterpret_cast<const char*>(d.X);
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -623,6 +627,49 @@ __device__ __forceinline__ void slab_load_half(const SlabStrip<T>& d, int h, int
         for (int j = 0; j < 4; ++j) {
             const int k = kstep(h, cc, j) + KLS * lk;
             x[4 * cc + j] = *reinterpret_cast<const cx<T>*>(base + (p0 + (unsigned)(k < ww ? k : ww - 1) * ks));
+        }
+}
+
+// BAND (see slab_multiply_half_3m): output tile q skips the k chunks c >= q + 2 of a chase unitary (compile-time conditions: h, cc, q are
+// unrolled constants)
+template <class T, int SIDE, bool BAND = false>
+__device__ __forceinline__ void slab_multiply_half(const T* __restrict__ Ur, const T* __restrict__ Ui, int h, int lane, const cx<T> (&x)[8],
+                                                   typename Mfma<T>::acc_t (&accR)[4], typename Mfma<T>::acc_t (&accI)[4]) {
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int chunk = 2 * h + cc;
+            const int off = (kstep(h, cc, j) + KLS * lk) * MLD + lr;
+            const T xr = x[4 * cc + j].x, xi = x[4 * cc + j].y;
+            T ur[4], ui[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (BAND && chunk >= q + 2) continue;
+                ur[q] = Ur[off + 16 * q]; ui[q] = Ui[off + 16 * q];
+            }
+            if (SIDE == 1) {          // C = X U:      Cr += xr ur - xi ui,  Ci += xr ui + xi ur          (A = x, B = u)
+                const T nxi = -xi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(xr, ur[q], accR[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xr, ui[q], accI[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(nxi, ui[q], accR[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(xi, ur[q], accI[q]);
+            } else {                  // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr          (A = conj(u)^T, B = x)
+                const T nxr = -xr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ur[q], xr, accR[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ur[q], xi, accI[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accR[q] = Mfma<T>::mma(ui[q], xi, accR[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(BAND && chunk >= q + 2)) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
+            }
         }
 }
 
@@ -669,7 +716,7 @@ __device__ __forceinline__ void slab_multiply_half_pair(const T* __restrict__ Ur
                 for (int q = 0; q < 2; ++q) if (q == 0 ? use0 : use1) accI[q] = Mfma<T>::mma(ui[q], nxr, accI[q]);
             }
             // bound the hoisting of the U fragment reads to the next two k-steps (register budget)
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            if (TRX_QR_VAR == 0 && (j & 1)) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
@@ -729,7 +776,7 @@ __device__ __forceinline__ void slab_multiply_half_3m(const T* __restrict__ Ur, 
         }
 }
 
-template <class T>
+template <class T, int SIDE = -1>
 __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, int w0, int ww, int lane, int pp, const typename Mfma<T>::acc_t (&accR)[2],
                                                 const typename Mfma<T>::acc_t (&accI)[2]) {
     const int lr = lane & 15;
@@ -741,7 +788,7 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
         for (int q2 = 0; q2 < 2; ++q2) {
             const int q = 2 * pp + q2;
             const cx<T> v(accR[q2][r], accI[q2][r]);
-            if (d.side == 1) {
+            if ((SIDE >= 0 ? SIDE : d.side) == 1) {
                 const int row = d.a0 + cr, k = 16 * q + lr;
                 if (row < d.lim && k < ww) *reinterpret_cast<cx<T>*>(base + ((unsigned)row * n + w0 + k) * (unsigned)sizeof(cx<T>)) = v;
             } else {
@@ -752,6 +799,9 @@ __device__ __forceinline__ void slab_store_pair(const SlabStrip<T>& d, int n, in
     }
 }
 
+template <class T, int SIDE>
+__device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0, int ww, int lane, const typename Mfma<T>::acc_t (&accR)[4],
+                                           const typename Mfma<T>::acc_t (&accI)[4]);
 template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]);
@@ -759,8 +809,8 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
 template <class T, int SIDE, bool BAND = false>
 __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane) {
     cx<T> xa[8], xb[8];
-    slab_load_half<T>(d, 0, n, w0, ww, lane, xa);
-    slab_load_half<T>(d, 1, n, w0, ww, lane, xb);
+    slab_load_half<T, SIDE>(d, 0, n, w0, ww, lane, xa);
+    slab_load_half<T, SIDE>(d, 1, n, w0, ww, lane, xb);
     __builtin_amdgcn_sched_barrier(0);       // keep all 16 loads of the strip in flight ahead of the first MFMA (hipcc otherwise sinks them to ~3 deep)
     slab_compute<T, SIDE, BAND>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
 }
@@ -769,7 +819,7 @@ __device__ __forceinline__ void slab_strip(const T* __restrict__ Ur, const T* __
 template <class T, int SIDE, bool BAND>
 __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane,
                                              const cx<T> (&xa)[8], const cx<T> (&xb)[8]) {
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (sizeof(T) == 8 || TRX_QR_VAR == 4) {
         // fp64: 3M product, two of the four output tiles at a time (the streamed operand stays in registers for both passes, the
         // U fragments of the second pass are other columns of the same LDS planes): 48 accumulator registers instead of 64, a
         // quarter fewer MFMAs -- the update sits at the HBM / matrix-core balance point, so this moves it onto the HBM side
@@ -790,8 +840,19 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
                     p1[q][r] = SIDE == 1 ? a - b : a + b;               // real part
                     p2[q][r] = SIDE == 1 ? c - a - b : c - a + b;       // imaginary part
                 }
-            slab_store_pair<T>(d, n, w0, ww, lane, pp, p1, p2);
+            slab_store_pair<T, SIDE>(d, n, w0, ww, lane, pp, p1, p2);
         }
+        return;
+    }
+    if constexpr (TRX_QR_VAR == 2 || TRX_QR_VAR == 3) {
+        typename Mfma<T>::acc_t accR[4], accI[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accR[q][r] = T(0); accI[q][r] = T(0); }
+        slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 0, lane, xa, accR, accI);
+        slab_multiply_half<T, SIDE, BAND>(Ur, Ui, 1, lane, xb, accR, accI);
+        slab_store<T, SIDE>(d, n, w0, ww, lane, accR, accI);
         return;
     }
     // fp32: 4M product (its error budget is the tight one), two of the four output tiles at a time: 16 accumulator registers, so that the
@@ -805,7 +866,31 @@ __device__ __forceinline__ void slab_compute(const T* __restrict__ Ur, const T* 
             for (int r = 0; r < 4; ++r) { accR[q][r] = T(0); accI[q][r] = T(0); }
         slab_multiply_half_pair<T, SIDE, BAND>(Ur, Ui, 0, pp, lane, xa, accR, accI);
         slab_multiply_half_pair<T, SIDE, BAND>(Ur, Ui, 1, pp, lane, xb, accR, accI);
-        slab_store_pair<T>(d, n, w0, ww, lane, pp, accR, accI);
+        slab_store_pair<T, SIDE>(d, n, w0, ww, lane, pp, accR, accI);
+    }
+}
+
+// Result register r of tile q:  right update: strip row crow(lane, r), window column 16q + (lane&15);
+//                               left update:  window row 16q + crow(lane, r), strip column lane&15.
+template <class T, int SIDE>
+__device__ __forceinline__ void slab_store(const SlabStrip<T>& d, int n, int w0, int ww, int lane, const typename Mfma<T>::acc_t (&accR)[4],
+                                           const typename Mfma<T>::acc_t (&accI)[4]) {
+    const int lr = lane & 15;
+    char* base = reinterpret_cast<char*>(d.X);       // scalar base + 32-bit byte offsets, as in slab_load_half
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cr = Mfma<T>::crow(lane, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const cx<T> v(accR[q][r], accI[q][r]);
+            if ((SIDE >= 0 ? SIDE : d.side) == 1) {
+                const int row = d.a0 + cr, k = 16 * q + lr;
+                if (row < d.lim && k < ww) *reinterpret_cast<cx<T>*>(base + ((unsigned)row * n + w0 + k) * (unsigned)sizeof(cx<T>)) = v;
+            } else {
+                const int i = 16 * q + cr, col = d.a0 + lr;
+                if (i < ww && col < d.lim) *reinterpret_cast<cx<T>*>(base + ((unsigned)(w0 + i) * n + col) * (unsigned)sizeof(cx<T>)) = v;
+            }
+        }
     }
 }
 
@@ -897,12 +982,11 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
     }
 }
 
-// waves per SIMD the window kernel is compiled for: LEAN (fp32) 8, i.e. <= 64 registers, so that it fits next to update workgroups (knob qr_regs)
-#define WINDOW_MIN_WG(T, LEAN) ((sizeof(T) == 4 && LEAN) ? 8 : 1)
-// DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it (it must stay within
-// 64 VGPRs: 4 of its waves share a SIMD's 512 registers with the waves of the update workgroups).
-template <class T, bool DBG, bool LEAN = false>
-__global__ __launch_bounds__(WTHREADS, WINDOW_MIN_WG(T, LEAN)) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
+// DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it.  (A 64-register build of the fp32
+// kernel -- so that its 4 waves per SIMD fit next to update workgroups -- spilled 45 registers in the band update and changed nothing:
+// profiles/r05_ab/r5h_occupancy.txt.)
+template <class T, bool DBG>
+__global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
                                                         int par, int nslot, int kc, int slot0, int nsteps, int band_on, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
@@ -1140,18 +1224,21 @@ __global__ __launch_bounds__(WTHREADS, WINDOW_MIN_WG(T, LEAN)) void qr_window_ke
     if (t == 0) st_all[b].tau[ch][par ^ (nsteps & 1)] = tau_cur;
 }
 
-// Waves per SIMD the update kernel is compiled for: 2 (<= 256 registers); LEAN (fp32, knob qr_regs) 4, i.e. <= 128 registers: two of its workgroups
-// then leave half of a SIMD's registers to the 4 waves of a lean window workgroup.
-#define APPLY_MIN_WG(T, LEAN) ((sizeof(T) == 4 && LEAN) ? 4 : 2)
+// Waves per SIMD the update kernel is compiled for: fp64 2 (<= 256 registers), fp32 3 (<= 168).  (4, i.e. <= 128 registers, spilled 26 - 47
+// and was not faster; a software-pipelined fp32 variant -- double-buffered U, two strips per wave, 240 registers -- was slower than this kernel
+// once its staging loads were batched: profiles/r05_ab/.)
+#define APPLY_MIN_WG(T) (sizeof(T) == 4 ? 3 : 2)
 
 // The update kernels walk over LINKS of the sweep's log (QrLink: window [w0, w1), kind, e = first column the left update still has to
 // reach; the window unitary sits in the same slot of the U log, that of a dense link in the per-matrix buffer the prepare kernel writes).
 //
-// MODE 0 -- right behind a window step, links [q0, q0 + nq) of chain blockIdx.x / units:
-//     chase link:  H[w0:w1, e:n) <- U^H H[w0:w1, e:n)            (the left update: the next window's new columns are among these)
-//     dense link:  the same + H[0:w0, w0:w1) <- H[0:w0, w0:w1) U + Z[:, w0:w1) <- Z[:, w0:w1) U   (unitary of an AED window / a finished
-//                  block: the chase that follows reads rows above that window, so nothing of it can wait)
+// MODE 0 -- right behind a super-step, the CHASE links among [q0, q0 + nq) of chain blockIdx.x / units:
+//     H[w0:w1, e:n) <- U^H H[w0:w1, e:n)            (the left update: the next window's new columns are among these)
+// MODE 2 -- slot 0 of a sweep, the DENSE link if there is one (unitary of an AED window / a finished block: the chase that follows reads rows
+//     above that window, so nothing of it can wait):  the left update + H[0:w0, w0:w1) <- H[0:w0, w0:w1) U + Z[:, w0:w1) <- Z[:, w0:w1) U
 //     A workgroup takes 4 * spw consecutive strips (its 4 waves interleaved, so that they stream neighbouring columns / rows).
+//     (Separate instantiations because the side of a strip is then a compile-time constant in MODE 0 and 1: no address arithmetic for the
+//     other side, ~40 registers less -- the fp32 kernels run 4 instead of 2 waves per SIMD.)
 // MODE 1 -- links [q0, q0 + nq) x all chains, in order, chase links only (`units` = parts: bit 0 rows of H, bit 1 rows of Z):
 //     H[0:w0, w0:w1) <- H[0:w0, w0:w1) U   and   Z[:, w0:w1) <- Z[:, w0:w1) U.
 //     A workgroup owns 64 ROWS (one 16-row strip per wave) of Z (the first blocks) or of H and takes them through every link whose
@@ -1160,8 +1247,8 @@ __global__ __launch_bounds__(WTHREADS, WINDOW_MIN_WG(T, LEAN)) void qr_window_ke
 //     on rows INSIDE a window, and no window of the sweep comes back to rows above an earlier one), and left / right multiplications
 //     commute, so the result is that of the interleaved order.  SEVERAL chains: a following chain's window does come back to rows the
 //     chain ahead has updated from the right, so the H part runs after every window step (nq = 1) and only Z waits for the end of the sweep.
-template <class T, int MODE, bool LEAN = false>
-__global__ __launch_bounds__(256, APPLY_MIN_WG(T, LEAN)) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
+template <class T, int MODE>
+__global__ __launch_bounds__(256, APPLY_MIN_WG(T)) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                           const QrLink* __restrict__ links_all, const cx<T>* __restrict__ Ulog_all,
                                                           const cx<T>* __restrict__ Udense_all, unsigned* __restrict__ work, int nslot, int kc,
                                                           int q0, int nq, int spw, int units, int band_on) {
@@ -1173,8 +1260,8 @@ __global__ __launch_bounds__(256, APPLY_MIN_WG(T, LEAN)) void apply_links_kernel
     const int b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // strip descriptors live in scalar registers
-    const int ch0 = MODE == 0 ? (int)blockIdx.x / units : 0;
-    const int gx = MODE == 0 ? (int)blockIdx.x - ch0 * units : (int)blockIdx.x;
+    const int ch0 = MODE != 1 ? (int)blockIdx.x / units : 0;
+    const int gx = MODE != 1 ? (int)blockIdx.x - ch0 * units : (int)blockIdx.x;
     const int unitsZ = (MODE == 1 && (units & 2)) ? (n + 63) >> 6 : 0;
     const bool isZ = MODE == 1 && gx < unitsZ;
     const int row0 = MODE == 1 ? 64 * (isZ ? gx : gx - unitsZ) : 0;     // MODE 1: first of this workgroup's 64 rows
@@ -1184,19 +1271,19 @@ __global__ __launch_bounds__(256, APPLY_MIN_WG(T, LEAN)) void apply_links_kernel
     __syncthreads();
     bool staged = false;                                              // LDS holds a U some wave may still be reading
     for (int qq = q0; qq < q0 + nq; ++qq)
-        for (int ch = (MODE == 0 ? ch0 : 0); ch < (MODE == 0 ? ch0 + 1 : kc); ++ch) {
+        for (int ch = (MODE != 1 ? ch0 : 0); ch < (MODE != 1 ? ch0 + 1 : kc); ++ch) {
             const QrLink* lp = lks + (qq - q0) * kc + ch;
             const int kind = __builtin_amdgcn_readfirstlane(lp->kind);
-            if (kind == QRL_NONE || (MODE == 1 && kind != QRL_CHASE)) continue;
+            if (kind != (MODE == 2 ? QRL_DENSE : QRL_CHASE)) continue;
             const int w0 = __builtin_amdgcn_readfirstlane(lp->w0), w1 = __builtin_amdgcn_readfirstlane(lp->w1);
             const int e = __builtin_amdgcn_readfirstlane(lp->e);
             const int ww = w1 - w0;
             if (ww <= 0) continue;
             // strips of this link that fall to this workgroup (everything here is workgroup-uniform)
             int nL = 0, nR = 0, nZ = 0, S = 0, g0 = 0;
-            if (MODE == 0) {
+            if (MODE != 1) {
                 nL = n > e ? (n - e + 15) >> 4 : 0;
-                if (kind == QRL_DENSE) { nR = (w0 + 15) >> 4; nZ = (n + 15) >> 4; }
+                if (MODE == 2) { nR = (w0 + 15) >> 4; nZ = (n + 15) >> 4; }
                 S = nL + nR + nZ;
                 g0 = gx * (4 * spw);
                 if (g0 >= S) continue;
@@ -1204,43 +1291,79 @@ __global__ __launch_bounds__(256, APPLY_MIN_WG(T, LEAN)) void apply_links_kernel
                 if (row0 >= (isZ ? n : w0)) continue;
             }
             if (gx == 0 && t == 0)      // algorithmic work of this link's update, in units of 4096 complex MACs
-                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (kind == QRL_DENSE ? 2L * n - ww : (long)(n > e ? n - e : 0)))) >> 12));
-            const cx<T>* U = kind == QRL_DENSE ? Udense_all + (long)b * QW * QW : Ulog_all + (((long)b * nslot + qq) * kc + ch) * QW * QW;
+                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (MODE == 2 ? 2L * n - ww : (long)(n > e ? n - e : 0)))) >> 12));
+            const cx<T>* U = MODE == 2 ? Udense_all + (long)b * QW * QW : Ulog_all + (((long)b * nslot + qq) * kc + ch) * QW * QW;
+            // Per link: (1) ALL global loads up front -- the 16 U elements of this thread and the first strip's 64 x 16 block (both only depend on
+            // what this wave itself stored for the previous link) -- (2) barrier: the previous link's readers are done with the planes, (3) U
+            // registers -> planes, (4) barrier, (5) MFMAs + stores.  (As a loop of load -> LDS store the staging was 16 dependent L2 round trips,
+            // ~25 us per link on the critical path of the link chain: measured, profiles/r05_ab/r5i_pmc_qr_updates.txt.)
+            cx<T> ureg[QW * QW / 256];
+#pragma unroll
+            for (int i = 0; i < QW * QW / 256; ++i) {
+                const int el = t + 256 * i, k = el >> 6, c = el & 63;
+                ureg[i] = U[(k < ww ? k : ww - 1) * QW + (c < ww ? c : ww - 1)];            // clamped: no branch around the load
+            }
+            // first strip of this wave
+            SlabStrip<T> d;
+            bool on = false;
+            if (MODE == 1) {
+                d.X = isZ ? Z : H; d.side = 1; d.a0 = row0 + 16 * wave; d.lim = isZ ? n : w0;
+                on = d.a0 < d.lim;
+            } else {
+                const int g = g0 + wave;
+                on = g < S;
+                if (MODE == 0 || g < nL) { d.X = H; d.side = 0; d.a0 = e + 16 * g; d.lim = n; }
+                else if (g < nL + nR) { d.X = H; d.side = 1; d.a0 = 16 * (g - nL); d.lim = w0; }
+                else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nL - nR); d.lim = n; }
+            }
+            cx<T> xa[8], xb[8];
+            if (on) {
+                slab_load_half<T, MODE == 2 ? -1 : (MODE == 1 ? 1 : 0)>(d, 0, n, w0, ww, lane, xa);
+                slab_load_half<T, MODE == 2 ? -1 : (MODE == 1 ? 1 : 0)>(d, 1, n, w0, ww, lane, xb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (staged) __syncthreads();                          // every wave is done with the previous link's planes
             int dense = 0;                                        // any nonzero in the blocks the banded product skips?
-            for (int el = t; el < QW * QW; el += 256) {
-                const int k = el >> 6, c = el & 63;
-                cx<T> u(T(0), T(0));
-                if (k < ww && c < ww) u = U[k * QW + c];
+#pragma unroll
+            for (int i = 0; i < QW * QW / 256; ++i) {
+                const int el = t + 256 * i, k = el >> 6, c = el & 63;
+                cx<T> u = ureg[i];
+                if (k >= ww || c >= ww) u = cx<T>(T(0), T(0));
                 Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
                 if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
             }
             { const int wd = __any(dense); if (lane == 0) wdense[t >> 6] = wd; }
             __syncthreads();
             staged = true;
-            const bool band = band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
-            if (MODE == 0) {
-                for (int i = 0; i < spw; ++i) {
-                    int g = g0 + wave + 4 * i;
-                    if (g >= S) break;
-                    SlabStrip<T> d;
-                    if (g < nL) { d.X = H; d.side = 0; d.a0 = e + 16 * g; d.lim = n; }
-                    else if (g < nL + nR) { d.X = H; d.side = 1; d.a0 = 16 * (g - nL); d.lim = w0; }
-                    else { d.X = Z; d.side = 1; d.a0 = 16 * (g - nL - nR); d.lim = n; }
-                    if (band) {
-                        if (d.side == 0) slab_strip<T, 0, true>(Ur, Ui, d, n, w0, ww, lane);
-                        else slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
-                    } else {
-                        if (d.side == 0) slab_strip<T, 0>(Ur, Ui, d, n, w0, ww, lane);
-                        else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
-                    }
+            const bool band = MODE != 2 && band_on && !(wdense[0] | wdense[1] | wdense[2] | wdense[3]);
+            if (on) {
+                if (MODE == 1) {
+                    if (band) slab_compute<T, 1, true>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+                    else slab_compute<T, 1, false>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+                } else if (MODE == 0) {
+                    if (band) slab_compute<T, 0, true>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+                    else slab_compute<T, 0, false>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+                } else {
+                    if (d.side == 0) slab_compute<T, 0, false>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
+                    else slab_compute<T, 1, false>(Ur, Ui, d, n, w0, ww, lane, xa, xb);
                 }
-            } else {
-                SlabStrip<T> d;
-                d.X = isZ ? Z : H; d.side = 1; d.a0 = row0 + 16 * wave; d.lim = isZ ? n : w0;
-                if (d.a0 < d.lim) {
-                    if (band) slab_strip<T, 1, true>(Ur, Ui, d, n, w0, ww, lane);
-                    else slab_strip<T, 1>(Ur, Ui, d, n, w0, ww, lane);
+            }
+            // further strips of this wave (MODE 0 / 2 with more than one strip per wave)
+            if (MODE != 1) {
+                for (int i = 1; i < spw; ++i) {
+                    const int g = g0 + wave + 4 * i;
+                    if (g >= S) break;
+                    SlabStrip<T> d2;
+                    if (MODE == 0 || g < nL) { d2.X = H; d2.side = 0; d2.a0 = e + 16 * g; d2.lim = n; }
+                    else if (g < nL + nR) { d2.X = H; d2.side = 1; d2.a0 = 16 * (g - nL); d2.lim = w0; }
+                    else { d2.X = Z; d2.side = 1; d2.a0 = 16 * (g - nL - nR); d2.lim = n; }
+                    if (MODE == 0) {
+                        if (band) slab_strip<T, 0, true>(Ur, Ui, d2, n, w0, ww, lane);
+                        else slab_strip<T, 0>(Ur, Ui, d2, n, w0, ww, lane);
+                    } else {
+                        if (d2.side == 0) slab_strip<T, 0>(Ur, Ui, d2, n, w0, ww, lane);
+                        else slab_strip<T, 1>(Ur, Ui, d2, n, w0, ww, lane);
+                    }
                 }
             }
         }
@@ -1260,7 +1383,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, lds = 0, regs = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1282,8 +1405,6 @@ static QrKnobs& qr_knobs() {
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
-        q.lds = geti("TRX_SLAB_LDS", 1, 150, 0);              // KB of LDS an update workgroup reserves (caps the workgroups per CU chip-wide); 0 = automatic
-        q.regs = geti("TRX_QR_REGS", 0, 3, 0);                // bit 0: lean (64-register) fp32 window kernel, bit 1: lean (128-register) fp32 update kernels
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1341,8 +1462,6 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
-    else if (s == "slab_lds") { slot = &k.lds; hi = 150; }
-    else if (s == "qr_regs") { slot = &k.regs; hi = 3; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1357,14 +1476,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const size_t smw = sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS + sizeof(QrState) + 16;      // + the band flag
     const int kc = qr_chains_for(batch);
     const int nslot = qr_log_slots(n);
-    // update kernel: the two planes of U, the four per-wave band votes, the launch's link records -- and, in fp32, a RESERVE up to 54 KB:
-    // two update workgroups (108 KB) then leave room for the 52 KB of a window workgroup on every CU, and a third one does not fit,
-    // whichever iteration group it comes from -- the latency-bound window kernels of the other groups never wait for a CU.
-    size_t sma = sizeof(T) * 2 * QW * MLD + 16 + sizeof(QrLink) * (size_t)nslot * kc;
-    {
-        const size_t reserve = (size_t)(K.lds ? K.lds : (sizeof(T) == 4 ? 54 : 0)) * 1024;
-        if (sma < reserve) sma = reserve;
-    }
+    // update kernel: the two planes of U, the four per-wave band votes, the launch's link records
+    const size_t sma = sizeof(T) * 2 * QW * MLD + 16 + sizeof(QrLink) * (size_t)nslot * kc;
     auto smp_of = [](int sm) { return sizeof(cx<T>) * (2 * (size_t)sm * (sm + 1) + 2 * sm) + sizeof(Rot<T>) * sm + sizeof(QrState); };
     // opt-in to > 64 KB of dynamic LDS: per (device, dtype), once; a failure is remembered so that no later call launches anyway
     static std::mutex attr_mu;
@@ -1375,11 +1488,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         std::lock_guard<std::mutex> lock(attr_mu);
         int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
         if (stt == 0) {
-            const size_t sma_max = 160 * 1024 - 512;     // (the reserve is a knob and the link records depend on n: opt in to the largest size once)
+            const size_t sma_max = 160 * 1024 - 512;     // (the link records depend on n: opt in to the largest size once)
             const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) ||
-                  set_max_dyn_smem((const void*)qr_window_kernel<T, false, true>, smw) ||
                   set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma_max) ||
-                  set_max_dyn_smem((const void*)apply_links_kernel<T, 0, true>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1, true>, sma_max) ||
+                  set_max_dyn_smem((const void*)apply_links_kernel<T, 2>, sma_max) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
             stt = r ? 2 : 1;
         }
@@ -1390,7 +1502,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     if (hipMemsetAsync(B.summary, 0, sizeof(int) * 64, s) != hipSuccess) return TRX_ERR_LAUNCH;
     const int max_sweeps = 30 * n + 100;
     // strips per wave of the per-step left update: small batches are latency bound and keep the shorter per-launch chain
-    const int spw = K.spw ? K.spw : (batch >= 64 ? 2 : 1);
+    const int spw = K.spw ? K.spw : 1;          // measured: 1 is best at every batch size (32.9 vs 32.4 layer-solves/s at batch 128 with 2)
     const int nstrip = cdiv_i(n, 16);
     const int adv = QW - 2 * QNS - 1;                        // guaranteed chain advance per window step
     // Bulge chains per sweep.  Measured on MI355X (n = 1922): 2 / 3 chains cut the outer iterations by only 31 / 36 % (the AED's
@@ -1401,7 +1513,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const int band_on = K.band != 1;
     // window steps per launch: the in-kernel band update exists in fp32 for one chain per sweep (the mixed-precision route's first stage)
     const int super = (sizeof(T) == 4 && kc == 1) ? (K.super ? K.super : 4) : 1;
-    const bool lean_w = sizeof(T) == 4 && (K.regs & 1), lean_a = sizeof(T) == 4 && (K.regs & 2);
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1500,13 +1611,15 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             const int ns = q == 0 ? 1 : (nwin - q < super ? nwin - q : super);
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
               if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, dbg_dev);
-              else if (lean_w) TRX_LAUNCH((qr_window_kernel<T, false, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, (long long*)nullptr);
               else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, (long long*)nullptr); }
             G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
-              const int units = cdiv_i(q == 0 ? 3 * nstrip + 3 : nstrip + 1, 4 * spw);
-              if (lean_a) TRX_LAUNCH((apply_links_kernel<T, 0, true>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
-              else TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
+              if (q == 0) {      // the dense link of slot 0, if there is one: left | right-H | Z, up to 3 n / 16 + 3 strips
+                  const int du = cdiv_i(3 * nstrip + 3, 4 * spw);
+                  TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on);
+              }
+              const int units = cdiv_i(nstrip + 1, 4 * spw);
+              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed)
               if (kc > 1)
                   TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 1, band_on); }
@@ -1517,8 +1630,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // deflation), so it cannot run beside it.
         { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
           const int parts = kc > 1 ? 2 : 3;
-          if (lean_a) TRX_LAUNCH((apply_links_kernel<T, 1, true>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on);
-          else TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
+          TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
         return true;
     };
     if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
