@@ -77,10 +77,11 @@ int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, int* info, v
  *   different host threads -- or a complex64 and a complex128 solver of one process -- cannot change each other's route or step count
  *   (torcwa_amd.Engine.eig uses these entry points; tests/test_eig.py::test_eig_opts_two_threads).  The workspace size depends on the route:
  *   size it with trx_eig_ws_bytes_opts and the SAME opts. */
-/* 1 if the calling thread's last trx_eig / trx_eig_opts ran the mixed-precision route and had to redo the batch in fp64 (a matrix with a
- * cluster of close eigenvalues beyond the refinement's exact treatment: symmetric meta-atoms, dense spectra of large orders), else 0.  The
- * library is stateless: a caller that solves a SEQUENCE of similar problems (the sweep drivers of torcwa_amd) uses this to ask for the all-fp64
- * route (opts bits 4-7 = 1) on the following calls instead of paying for the failed attempt every time. */
+/* Number of matrices of the calling thread's last trx_eig / trx_eig_opts that the mixed-precision route could not certify and redid with the
+ * all-fp64 pipeline (a cluster of close eigenvalues beyond the refinement's exact treatment: symmetric meta-atoms, dense spectra of large
+ * orders; an fp32 result too far off; a singular eigenvector matrix).  Up to a third of the batch is redone as a compact sub-batch inside
+ * the same workspace, beyond that the whole batch (the count is then `batch`); 0 = nothing was redone.  Diagnostic only: results do not
+ * depend on it, and the library keeps no state between calls. */
 int trx_eig_last_fallback(void);
 size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts);
 int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, void* stream, unsigned opts);

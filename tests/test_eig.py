@@ -402,42 +402,42 @@ def test_eig_opts_two_threads():
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_eig_route_memory_after_fallback(backend):
-    """A matrix with a ten-fold eigenvalue makes the mixed route redo its batch in fp64 (trx_eig_last_fallback reports it on the calling
-    thread); torcwa_amd.Engine remembers that for the size and asks for the all-fp64 route on the following calls (no second failed attempt),
-    re-probes after EIG_REPROBE calls, and forgets the hint when the probe goes through.  Results are right on every call."""
-    import torch
+def test_eig_partial_fallback_is_per_matrix(backend):
+    """A batch in which ONE matrix has a ten-fold eigenvalue (beyond the refinement's exact cluster treatment): the mixed route keeps its
+    refined results for the other matrices and redoes only the flagged one in fp64, as a compact sub-batch inside the same workspace
+    (trx_eig_last_fallback = number of matrices redone, on the calling thread).  No host-side route memory: the same call sequence in any
+    order gives the same answers, and a batch without hard matrices reports 0 right after one with."""
     from tests.test_pipeline import make_engine
+    import torch
     eng = make_engine(backend)
+    be = get_backend(backend)
     n = 40 if backend == "emu" else 300
     rng = np.random.default_rng(5)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
     lam = 2.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     lam[:10] = 1.5 - 0.5j
-    hard = torch.from_numpy(((Q * lam[None, :]) @ Q.conj().T)[None].astype(np.complex128)).to(eng.device)
-    easy = torch.from_numpy((rng.standard_normal((1, n, n)) + 1j * rng.standard_normal((1, n, n))).astype(np.complex128)).to(eng.device)
-
-    def solve(A):
-        w, V = eng.eig(A)
-        r = (torch.linalg.norm(A @ V - V * w[:, None, :]) / torch.linalg.norm(A)).item()
-        assert r < 1e-11, r
-
-    eng._eig_route_hint.clear()
-    old_reprobe, be = eng.EIG_REPROBE, get_backend(backend)
+    hard = (Q * lam[None, :]) @ Q.conj().T
+    A = (rng.standard_normal((6, n, n)) + 1j * rng.standard_normal((6, n, n))).astype(np.complex128)
+    A[4] = hard                                         # 1 of 6 flagged: sub-batch of one
+    A[1] = 0.3 * A[1] + np.diag(np.linspace(-9, 9, n))
     try:
         _set_knobs(be, eig_vec=3)                    # mixed wherever n >= 8 (the automatic route needs n >= 256 and batch >= 8)
-        eng.EIG_REPROBE = 3
-        solve(easy)
-        assert not eng._eig_route_hint and eng.lib.eig_last_fallback() == 0
-        solve(hard)                                  # falls back -> remembered
-        assert eng.lib.eig_last_fallback() == 1 and (n, torch.complex128) in eng._eig_route_hint
-        solve(hard)                                  # forced fp64: no mixed attempt, hence no fallback report
-        assert eng.lib.eig_last_fallback() == 0 and (n, torch.complex128) in eng._eig_route_hint
-        solve(easy)                                  # still forced
-        assert (n, torch.complex128) in eng._eig_route_hint
-        solve(easy)                                  # third call since: re-probe on the automatic route, goes through -> hint dropped
-        assert (n, torch.complex128) not in eng._eig_route_hint
+        w, V, info = run_eig(be, A)
+        assert be.lib.eig_last_fallback() == 1
+        for b in range(6):
+            assert info[b] == 0
+            assert np.abs(A[b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A[b]).max() < 1e-12, b
+            assert np.allclose(np.linalg.norm(V[b], axis=0), 1.0, atol=1e-12)
+        w, V, info = run_eig(be, A[:4])              # no hard matrix: nothing redone, nothing remembered
+        assert be.lib.eig_last_fallback() == 0
+        A2 = A.copy(); A2[0] = hard; A2[2] = hard    # 3 of 6 flagged: more than a third -> the whole batch is redone
+        w, V, info = run_eig(be, A2)
+        assert be.lib.eig_last_fallback() == 6
+        for b in range(6):
+            assert info[b] == 0 and np.abs(A2[b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A2[b]).max() < 1e-12, b
+        At = torch.from_numpy(A).to(eng.device) if backend == "gpu" else None
+        if At is not None:                           # the engine reports the same count and keeps no route state
+            eng.eig(At)
+            assert eng.last_eig_fallback == 1 and not hasattr(eng, "_eig_route_hint")
     finally:
-        eng.EIG_REPROBE = old_reprobe
-        eng._eig_route_hint.clear()
         _set_knobs(be, eig_vec=0)

@@ -71,6 +71,12 @@ exp = torch.complex(torch.arange(M, dtype=torch.float64), -2 * torch.arange(M, d
 assert full.shape == (M, 3) and torch.equal(full, exp), (rank, full)
 r = gather_sweep(idx[:, None], M)
 assert torch.equal(r[:, 0], torch.arange(M, dtype=torch.float64))
+# cyclic sharding (SURVEY.md 8(e)): rank r solves points r, r + world, ...; the gather restores sweep order
+from torcwa_amd.sweep import shard_indices
+mine = torch.as_tensor(shard_indices(M, rank, world, cyclic=True), dtype=torch.float64)
+assert len(mine) == (6 if rank == 0 else 5) and float(mine[0]) == rank
+fullc = gather_sweep(torch.complex(mine, -2 * mine)[:, None].repeat(1, 3), M, cyclic=True)
+assert fullc.shape == (M, 3) and torch.equal(fullc, exp), (rank, fullc)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -86,6 +92,52 @@ def test_sweep_gather_two_ranks_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ok") >= 2
+
+
+def test_shard_indices_cover_the_sweep():
+    from torcwa_amd.sweep import shard_indices
+    for n in (0, 1, 7, 4096, 4099):
+        for w in (1, 3, 8):
+            for cyc in (False, True):
+                parts = [shard_indices(n, r, w, cyclic=cyc) for r in range(w)]
+                assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+                assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_auto_chunk_fits_free_memory(monkeypatch):
+    """solve_stack_sweep(chunk=None) sizes its lock-step chunk from the free HBM (15 / 18 n x n complex128 matrices per point, 10 % of the
+    device kept free) and says so, with numbers, when not even one point fits."""
+    from torcwa_amd import sweep
+    dev = torch.device("cuda", 0)
+    gb = 1e9
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda d=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: 0)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(280 * gb), int(288 * gb)))
+    assert sweep.auto_chunk(128, [15, 15], 1, "high", dev) == 128                  # config 2: the whole sweep
+    c4 = sweep.auto_chunk(4096, [15, 15], 1, "high", dev)                          # config 4's 4096 points: cut to what fits
+    assert 200 <= c4 <= 296 and c4 % 8 == 0
+    c3 = sweep.auto_chunk(64, [21, 21], 4, "high", dev)                            # config 3: [21,21], 4 layers
+    per = 18 * 3698 ** 2 * 16
+    assert 8 <= c3 <= 64 and c3 * per <= (280 - 28.8) * gb
+    assert sweep.auto_chunk(4096, [15, 15], 1, "native", dev) >= 2 * c4 - 8        # fp32 arithmetic: half the bytes
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(30 * gb), int(288 * gb)))
+    with pytest.raises(RuntimeError, match="needs about"):
+        sweep.auto_chunk(64, [21, 21], 4, "high", dev)
+    assert sweep.auto_chunk(77, [15, 15], 1, "high", torch.device("cpu")) == 77
+
+
+def test_homogeneity_rule_matches_the_reference():
+    """rcwa.py:156-157: float / complex / 0-d tensor / 1-D tensor of length 1 are homogeneous; python ints raise; any other 1-D tensor is not
+    homogeneous (batched extension: length B = one value per sweep point)."""
+    from torcwa_amd.batched import BatchedRCWA
+    obj = BatchedRCWA.__new__(BatchedRCWA)
+    obj.B = 1
+    assert obj._is_homogeneous(2.0) and obj._is_homogeneous(2j) and obj._is_homogeneous(torch.tensor(2.0)) and obj._is_homogeneous(torch.tensor([2.0]))
+    assert not obj._is_homogeneous(torch.tensor([2.0, 3.0, 4.0])) and not obj._is_homogeneous(torch.ones(4, 4))
+    with pytest.raises(AttributeError):
+        obj._is_homogeneous(2)
+    obj.B = 3
+    assert obj._is_homogeneous(torch.tensor([2.0, 3.0, 4.0])) and not obj._is_homogeneous(torch.tensor([2.0, 3.0]))
 
 
 def test_blockdiag2_algebra():

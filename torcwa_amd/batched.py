@@ -382,7 +382,9 @@ class BatchedRCWA:
         if isinstance(v, int):                     # the reference raises AttributeError here (rcwa.py:156)
             raise AttributeError("'int' object has no attribute 'dim'")
         t = torch.as_tensor(v)
-        return t.dim() == 0 or t.dim() == 1
+        # rcwa.py:156-157: a 0-d tensor or a 1-D tensor of length 1.  Batched extension: a 1-D tensor of length B is one homogeneous value per
+        # sweep point; any other 1-D tensor is NOT homogeneous, exactly as in the reference (it then fails in the grid path like there).
+        return t.dim() == 0 or (t.dim() == 1 and t.shape[0] in (1, self.B))
 
     def _solve_layer_smatrix(self):                                                     # rcwa.py:1244-1281
         eng = self.engine

@@ -6,6 +6,7 @@
 #include "eig.hpp"
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 namespace trx {
 
@@ -21,7 +22,7 @@ static int g_eig_vec = eig_vec_env();      // trx_tuning("eig_vec", v): 0 automa
 // call on the calling host thread -- the process-global knobs are only the defaults, so two threads (or a complex64 and a complex128 solver
 // in one process) can no longer overwrite each other's setting between trx_tuning and trx_eig.  -1 = not set (use the knob).
 static thread_local int tl_eig_vec = -1, tl_refine = -1;
-static thread_local int tl_last_fallback = 0;      // the calling thread's last trx_eig: 1 = the mixed route was redone in fp64 (trx_eig_last_fallback)
+static thread_local int tl_last_fallback = 0;      // the calling thread's last trx_eig: number of matrices the mixed route redid in fp64 (trx_eig_last_fallback)
 static inline int cur_eig_vec() { return tl_eig_vec >= 0 ? tl_eig_vec : g_eig_vec; }
 struct EigCallOpts {
     EigCallOpts(unsigned opts) { const int r = opts & 0xF, v = (opts >> 4) & 0xF; tl_refine = r ? r : -1; tl_eig_vec = v ? v : -1; }
@@ -160,8 +161,62 @@ __global__ __launch_bounds__(256) void clear_below_subdiag_kernel(cx<T>* __restr
 template <class T>
 int eig_after_balance(hipStream_t s, const EigBuffers<T>& B, void* w, void* V, int n, int batch, int* info);
 
+// gather / scatter of whole matrices and rows by an index list (sub-batch of the mixed route's fallback)
 template <class T>
-int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info, void* ws) {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ idx, long row, int to_compact) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row) return;
+    const long j = blockIdx.y, b = idx[j];
+    if (to_compact) dst[j * row + i] = src[b * row + i];
+    else dst[b * row + i] = src[j * row + i];
+}
+
+// All-fp64 solve of the matrices bad[b] != 0 (nf of them) as ONE compact sub-batch inside the caller's workspace: the sub-batch's own buffers
+// (eig_carve for nf matrices) at the front, its input copies / outputs / index list at the tail.  TRX_ERR_WORKSPACE: no room (the caller then
+// redoes the whole batch).  bal_d: the scaling of the whole batch (its rows are gathered for the undo of the balancing).
+template <class T>
+int eig_redo_subset(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, const T* bal_d, const std::vector<int>& bad, int nf) {
+    const size_t e = sizeof(cx<T>), N = n, NF = nf;
+    struct RouteGuard { int save; RouteGuard() : save(tl_eig_vec) { tl_eig_vec = 1; } ~RouteGuard() { tl_eig_vec = save; } } guard;      // the sub-batch: all-fp64 layout and route
+    const size_t front = eig_ws_bytes_t<T>(n, nf);
+    const size_t tail = al256(e * NF * N * N) * 2 + al256(e * NF * N) + al256(sizeof(T) * NF * N) + al256(sizeof(int) * NF) * 2;
+    if (front + tail > ws_bytes) return TRX_ERR_WORKSPACE;
+    char* p = (char*)ws + ws_bytes - tail;
+    p = (char*)(((size_t)p) & ~(size_t)255);
+    if (p < (char*)ws + front) return TRX_ERR_WORKSPACE;
+    auto take = [&](size_t bytes) { char* q = p; p += al256(bytes); return q; };
+    // the small pieces first (they sit at the very end of the workspace, in what the refinement's tables occupied), then the big ones
+    char* p_save = p;
+    p = p_save + al256(e * NF * N * N) * 2;
+    cx<T>* wsub = (cx<T>*)take(e * NF * N);
+    T* dsub = (T*)take(sizeof(T) * NF * N);
+    int* idx = (int*)take(sizeof(int) * NF);
+    int* isub = (int*)take(sizeof(int) * NF);
+    p = p_save;
+    cx<T>* Asub = (cx<T>*)take(e * NF * N * N);
+    cx<T>* Vsub = (cx<T>*)take(e * NF * N * N);
+    std::vector<int> hidx;
+    for (int b = 0; b < batch; ++b) if (bad[b]) hidx.push_back(b);
+    if ((int)hidx.size() != nf) return TRX_ERR_ARG;
+    if (hipMemcpyAsync(idx, hidx.data(), sizeof(int) * NF, hipMemcpyHostToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;          // (hidx is a host temporary)
+    TRX_LAUNCH((gather_rows_kernel<T>), dim3(cdiv_i(n, 256), nf), dim3(256), 0, s, bal_d, dsub, (const int*)idx, (long)n, 1);
+    TRX_LAUNCH((gather_rows_kernel<cx<T>>), dim3(cdiv_i((long)n * n, 256), nf), dim3(256), 0, s, (const cx<T>*)A, Asub, (const int*)idx, (long)n * n, 1);
+    EigBuffers<T> S;
+    eig_carve<T>(S, Asub, ws, n, nf);
+    if (hipMemcpyAsync(S.bal_d, dsub, sizeof(T) * NF * N, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (hipMemsetAsync(isub, 0, sizeof(int) * NF, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    int rc = eig_after_balance<T>(s, S, wsub, Vsub, n, nf, isub);
+    if (rc) return rc;
+    TRX_LAUNCH((gather_rows_kernel<cx<T>>), dim3(cdiv_i(n, 256), nf), dim3(256), 0, s, (const cx<T>*)wsub, (cx<T>*)w, (const int*)idx, (long)n, 0);
+    TRX_LAUNCH((gather_rows_kernel<cx<T>>), dim3(cdiv_i((long)n * n, 256), nf), dim3(256), 0, s, (const cx<T>*)Vsub, (cx<T>*)V, (const int*)idx, (long)n * n, 0);
+    TRX_LAUNCH((gather_rows_kernel<int>), dim3(1, nf), dim3(256), 0, s, (const int*)isub, info, (const int*)idx, 1L, 0);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template <class T>
+int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes) {
     EigBuffers<T> B;
     eig_carve<T>(B, A, ws, n, batch);
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
@@ -179,19 +234,28 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             cx<float>* w32 = (cx<float>*)p;
             rc = eig_mixed_convert(s, (const cx<double>*)A, A32, (long)Bn * N * N);
             if (rc) return rc;
-            rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32);      // its info reaches eig_refine in R.linfo and is folded into the flags there
+            rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32, eig_ws_bytes_f32(n, batch));      // its info reaches eig_refine in R.linfo and is folded into the flags there
             if (rc) return rc;
             RefineBuffers<T> R;
             R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;
             R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
             int any = 0;
+            std::vector<int> bad(batch, 0);
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
-            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any);
+            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any, bad.data());
             if (rc) return rc;
-            tl_last_fallback = any ? 1 : 0;
+            tl_last_fallback = any;
             if (!any) return finish_vectors<T>(s, B, n, batch, (cx<T>*)V);
-            // some matrix has a cluster of more than two eigenvalues, an fp32 result that is too far off, or a singular V: redo the batch
-            // in fp64 (A is still the balanced input, the scaling D is kept)
+            // Some matrices have a cluster beyond the exact treatment, an fp32 result that is too far off, or a singular V: redo THOSE in fp64
+            // as a compact sub-batch (A is still the balanced input, the scaling D is kept) when they are few and the workspace has room for
+            // the sub-batch next to its own buffers; otherwise the whole batch.
+            if (3 * any <= batch) {
+                rc = finish_vectors<T>(s, B, n, batch, (cx<T>*)V);          // everybody (the flagged ones are overwritten below); last reader of B
+                if (rc) return rc;
+                rc = eig_redo_subset<T>(s, A, w, V, n, batch, info, ws, ws_bytes, B.bal_d, bad, any);
+                if (rc != TRX_ERR_WORKSPACE) return rc;
+            }
+            tl_last_fallback = batch;
         }
     }
     return eig_after_balance<T>(s, B, w, V, n, batch, info);
@@ -323,5 +387,5 @@ extern "C" int trx_eig(int dtype, void* A, void* w, void* V, int n, int batch, i
     if (ws_bytes < trx_eig_ws_bytes(dtype, n, batch)) return TRX_ERR_WORKSPACE;
     hipStream_t s = trx::api_stream(stream);
     trx::tl_last_fallback = 0;
-    return dtype == TRX_C128 ? trx::eig_t<double>(s, A, w, V, n, batch, info, ws) : trx::eig_t<float>(s, A, w, V, n, batch, info, ws);
+    return dtype == TRX_C128 ? trx::eig_t<double>(s, A, w, V, n, batch, info, ws, ws_bytes) : trx::eig_t<float>(s, A, w, V, n, batch, info, ws, ws_bytes);
 }

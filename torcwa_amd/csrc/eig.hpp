@@ -87,7 +87,7 @@ struct RefineBuffers {
 };
 constexpr size_t REFINE_CLUSTER_BYTES = 280 * 1024;
 template <class T> int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const cx<float>* V32, const cx<float>* w32, cx<T>* w, cx<T>* V,
-                                  int n, int batch, int steps, int* host_any);
+                                  int n, int batch, int steps, int* host_any, int* host_bad);
 int refine_set_knob(const char* key, int value);
 int refine_steps();
 

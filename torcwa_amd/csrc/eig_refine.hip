@@ -11,8 +11,8 @@
 // the formula is not applied.  The connected components of the coupling graph (the degenerate mode pairs of symmetric meta-atoms; at
 // n = 1922 up to ~150 indices in pairs and the odd triple left by the fp32 start) are diagonalised exactly from their blocks of G by a small
 // dense solver; a component of more than 8 indices, more than 1024 coupled indices, a defective block, an off-diagonal part that is not
-// small, or a failed LU flag the matrix, and trx_eig then redoes the batch with the all-fp64 pipeline (the balanced input is kept
-// intact for that).
+// small, or a failed LU flag the matrix, and trx_eig then redoes THOSE matrices with the all-fp64 pipeline as a compact sub-batch (the
+// balanced input is kept intact for that; eig.hip).
 // Measured (MI355X, bench operator, n = 1922): the fp32 start leaves max |E| = 2e-2 ... 2e-1 (|lambda| up to 2.6e3); after one step 2.4e-4,
 // which is NOT yet inside the 1e-5 gate of a complex64 problem for every S-parameter; after two steps the complex64 and complex128 parity
 // tests pass (1e-5 / 1e-9 against the reference fixtures).  Steps: knob eig_refine (library default 2; torcwa_amd asks for 3 on behalf of
@@ -370,10 +370,11 @@ __global__ void refine_fold_info_kernel(int* __restrict__ flags, const int* __re
     if (b < batch && info32[b] != 0) atomicOr(&flags[b], 1);
 }
 
+// any[0] = number of matrices with a flag or a failed LU;  bad[b] = 1 for those (nullable)
 template <class T>
 __global__ void refine_or_info_kernel(const int* __restrict__ flags, const int* __restrict__ linfo, int* __restrict__ any, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < batch && (flags[b] != 0 || linfo[b] != 0)) atomicOr(any, 1);
+    if (b < batch && (flags[b] != 0 || linfo[b] != 0)) atomicAdd(any, 1);
 }
 
 }  // namespace
@@ -387,10 +388,12 @@ int refine_set_knob(const char* key, int value) {
 int refine_steps() { return g_refine_steps; }
 
 // A: balanced fp64 input (kept intact); V32 / w32: its fp32 eigendecomposition.  On return w, V hold the refined fp64 eigenpairs of A
-// (unit 2-norm is restored by the caller together with the undo of the balancing); *host_any != 0: some matrix was flagged.
+// (unit 2-norm is restored by the caller together with the undo of the balancing); *host_any = number of flagged matrices (their results are
+// not to be used: host_bad[b] != 0, one entry per matrix).  When EVERY matrix is flagged after the first scan the remaining steps are skipped.
 template <class T>
 int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const cx<float>* V32, const cx<float>* w32, cx<T>* w, cx<T>* V, int n, int batch, int steps,
-               int* host_any) {
+               int* host_any, int* host_bad) {
+    static const bool debug = getenv("TRX_EIG_DEBUG") != nullptr;          // read once per process (never per call)
     const cx<T> one(T(1), T(0)), zero(T(0), T(0));
     const long nn = (long)n * n;
     cx<T>* buf[2] = {V, R.V1};
@@ -408,31 +411,43 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         if (hipMemcpyAsync(Vn, Vc, sizeof(cx<T>) * cntV, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_LAUNCH;
         rc = lu_factor<T>(s, Vn, n, nn, n, R.piv, batch, R.linfo); if (rc) return rc;
         rc = lu_solve<T>(s, Vn, n, nn, n, R.piv, R.G, n, nn, n, batch); if (rc) return rc;
-        TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
+        TRX_LAUNCH(refine_fold_info_kernel, dim3(cdiv_i(batch, 64)), dim3(64), 0, s, R.flags, (const int*)R.linfo, batch);      // a singular V of THIS step: the next LU overwrites linfo
         TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.d0, R.eoff, R.lmax);
         TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<T>*)R.G, (const cx<T>*)w, n, (const T*)R.eoff, (const T*)R.lmax, R.partner, R.flags);
         TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), 0, s, (const cx<T>*)R.G, n, w, (const int*)R.partner, R.clus, (RefineClusters<T>*)R.pairX, R.flags);
-        if (it == 0) {
+        if (it == 0 && steps > 1) {
             // A matrix the scheme cannot certify (far-off start, a cluster beyond the exact treatment, singular V) is known after the FIRST
-            // scan, and the whole batch is then redone by the all-fp64 pipeline: stop here instead of finishing Newton steps whose result is
-            // thrown away (symmetric meta-atoms and the dense spectra of large orders raise the flag for a third of a sweep: configs 3, 4).
+            // scan.  Flagged matrices are redone by the all-fp64 pipeline afterwards (as a sub-batch); when more than a third of the batch is
+            // flagged the caller redoes the whole batch instead, so the remaining Newton steps would be thrown away: stop here.
+            if (hipMemsetAsync(R.flags + batch, 0, sizeof(int), s) != hipSuccess) return TRX_ERR_LAUNCH;
             TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
             if (hipMemcpyAsync(host_any, R.flags + batch, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
             if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
-            if (*host_any && !getenv("TRX_EIG_DEBUG")) return TRX_OK;
+            if (3 * *host_any > batch && !debug) {
+                for (int b = 0; b < batch; ++b) host_bad[b] = 1;
+                return TRX_OK;
+            }
         }
         TRX_LAUNCH((refine_build_clusters_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus, (const RefineClusters<T>*)R.pairX);
         TRX_LAUNCH((refine_build_inplace_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, R.G, n, (const cx<T>*)R.d0, (const int*)R.clus);
         rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, n, n, one, Vc, n, nn, R.G, n, nn, zero, Vn, n, nn, batch); if (rc) return rc;
         cur ^= 1;
     }
-    TRX_LAUNCH((refine_or_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const int*)R.flags, (const int*)R.linfo, R.flags + batch, batch);
-    if (hipMemcpyAsync(host_any, R.flags + batch, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
-    if (getenv("TRX_EIG_DEBUG")) {
+    {
+        // per-matrix verdict: flags (accumulated over the steps) or a failed LU of the last step
+        std::vector<int> hf(batch), hl(batch);
+        if (hipMemcpyAsync(hf.data(), R.flags, sizeof(int) * batch, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(hl.data(), R.linfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s) != hipSuccess) return TRX_ERR_LAUNCH;
+        if (hipStreamSynchronize(s) != hipSuccess) return TRX_ERR_LAUNCH;
+        int cnt = 0;
+        for (int b = 0; b < batch; ++b) { host_bad[b] = (hf[b] != 0 || hl[b] != 0); cnt += host_bad[b]; }
+        *host_any = cnt;
+    }
+    if (debug) {
         std::vector<int> hf(batch + 1), hl(batch);
         std::vector<T> he(batch), hm(batch);
-        (void)hipMemcpy(hf.data(), R.flags, sizeof(int) * (batch + 1), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hf.data(), R.flags, sizeof(int) * batch, hipMemcpyDeviceToHost);
+        hf[batch] = *host_any;
         (void)hipMemcpy(hl.data(), R.linfo, sizeof(int) * batch, hipMemcpyDeviceToHost);
         (void)hipMemcpy(he.data(), R.eoff, sizeof(T) * batch, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hm.data(), R.lmax, sizeof(T) * batch, hipMemcpyDeviceToHost);
@@ -453,6 +468,6 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
     return TRX_OK;
 }
 
-template int eig_refine<double>(hipStream_t, const RefineBuffers<double>&, const cx<double>*, const cx<float>*, const cx<float>*, cx<double>*, cx<double>*, int, int, int, int*);
+template int eig_refine<double>(hipStream_t, const RefineBuffers<double>&, const cx<double>*, const cx<float>*, const cx<float>*, cx<double>*, cx<double>*, int, int, int, int*, int*);
 
 }  // namespace trx

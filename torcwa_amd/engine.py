@@ -22,8 +22,6 @@ class NumericalError(RuntimeError):
 
 
 class Engine:
-    EIG_REPROBE = 32        # every EIG_REPROBE-th eig call of a size with a fallback on record tries the automatic route again
-
     def __init__(self, lib=None, device=None):
         if lib is None:
             lib = _lib.lib()                       # raises TrxError if libtrx.so has not been built
@@ -37,8 +35,7 @@ class Engine:
         self.device = torch.device(device if device is not None else "cpu")
         self.check_info = True
         self._fail_acc = {}            # per host thread: device-side count of non-zero info entries seen while check_info is False
-        self._eig_route_hint = {}      # (n, dtype) -> [1, calls since]: sizes whose mixed-precision attempt fell back to fp64 (see eig())
-        self._hint_lock = threading.Lock()          # the sweep drivers may call eig() from several host threads
+        self.last_eig_fallback = 0
 
     # -- helpers ---------------------------------------------------------------------------------------
     @property
@@ -156,20 +153,8 @@ class Engine:
         max |E| ~ 2e-2 ... 2e-1 there)."""
         self._check(A)
         opts = int(refine_steps) & 0xF          # per-call option word of trx_eig_opts (no process-global knob is touched: thread-safe)
-        # Route memory (host-side policy; the library itself is stateless): when the mixed-precision route had to redo a batch of this
-        # size in fp64 -- clusters of close eigenvalues beyond the refinement's exact treatment, as symmetric meta-atoms and the dense
-        # spectra of large orders produce them -- the following calls of the same (n, dtype) ask for the all-fp64 route directly instead of
-        # paying for the failed attempt every time (measured on MI355X: config 4 at chunk 256 17.6 -> 33.7 layer-solves/s, config 3
-        # 2.3 -> 3.9).  Every EIG_REPROBE-th such call tries the automatic route again.
-        key = (int(A.shape[-1]), A.dtype)
-        forced = False
-        with self._hint_lock:
-            hint = self._eig_route_hint.get(key)
-            if hint is not None and os.environ.get("TRX_EIG_VEC", "0") == "0":
-                hint[1] += 1
-                if hint[1] % self.EIG_REPROBE != 0:
-                    opts |= 1 << 4
-                    forced = True
+        # (No route policy lives here any more: matrices the mixed-precision route cannot certify -- clusters of close eigenvalues beyond the
+        # refinement's exact treatment -- are redone in fp64 INSIDE the library, as a sub-batch; results do not depend on call history.)
         A = self._c(A) if destroy else A.clone()
         B, n, _ = A.shape
         dt = A.dtype
@@ -179,13 +164,7 @@ class Engine:
         nws = self.lib.eig_ws_bytes_opts(_CODE[dt], n, B, opts)
         ws = self._ws(nws)
         self.lib.check(self.lib.eig_opts(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream, opts))
-        if not forced:
-            fell_back = bool(self.lib.eig_last_fallback())          # thread-local in the library: this thread's call
-            with self._hint_lock:
-                if fell_back:
-                    self._eig_route_hint.setdefault(key, [1, 0])
-                elif hint is not None:
-                    self._eig_route_hint.pop(key, None)     # the re-probe went through: back to the automatic route
+        self.last_eig_fallback = int(self.lib.eig_last_fallback())      # matrices of this call redone in fp64 (diagnostic; thread-local in the library)
         self._info(info, "eig")
         return w, V
 

@@ -2,8 +2,10 @@
 example/Example3.ipynb (Wx,Wy) sweep) as one batched, optionally multi-GPU job.
 
 Sharding: sweep points are independent, so rank r of R owns a contiguous block of the flattened sweep
-(`shard_range`); there is no data-path collective.  The only communication is one all_gather of the requested
-S-parameters at the end (`gather_sweep`, RCCL over xGMI on GPUs; payload is a few KB, latency-bound).
+(`shard_range`) -- or, when the cost of a point varies along the sweep (geometry sweeps: eigensolver iteration counts and
+fp64 re-solves differ per shape), every R-th point (`shard_indices(..., cyclic=True)`); there is no data-path
+collective.  The only communication is one all_gather of the requested S-parameters at the end (`gather_sweep`, RCCL over xGMI
+on GPUs; payload is a few KB, latency-bound).
 """
 import os
 
@@ -22,15 +24,25 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_sweep(local, n_items, group=None):
-    """all_gather of per-point results: `local` is this rank's [m_r, ...] block (m_r from shard_range).  Returns the
-    full [n_items, ...] tensor on every rank.  Works with unequal block sizes (pads to the largest block)."""
+def shard_indices(n_items, rank, world, cyclic=False):
+    """Global indices (numpy int64, ascending) of the sweep points rank `rank` solves: the contiguous block of `shard_range`, or
+    rank, rank + world, rank + 2 world, ... (cyclic: neighbouring points -- similar cost -- go to different ranks)."""
+    if cyclic:
+        return np.arange(int(rank), int(n_items), int(world), dtype=np.int64)
+    lo, hi = shard_range(n_items, rank, world)
+    return np.arange(lo, hi, dtype=np.int64)
+
+
+def gather_sweep(local, n_items, group=None, cyclic=False):
+    """all_gather of per-point results: `local` is this rank's [m_r, ...] block, in the order of shard_indices(n_items, rank, world,
+    cyclic).  Returns the full [n_items, ...] tensor in sweep order on every rank.  Works with unequal block sizes (pads to the largest)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [shard_range(n_items, r, world) for r in range(world)]
-    mmax = max(hi - lo for lo, hi in sizes)
+    counts = [len(shard_indices(n_items, r, world, cyclic)) for r in range(world)]
+    sizes = [(0, c) for c in counts]
+    mmax = max(counts)
     pad = torch.zeros((mmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     if pad.is_complex():
@@ -43,7 +55,13 @@ def gather_sweep(local, n_items, group=None):
     for r, (lo, hi) in enumerate(sizes):
         t = out[r][: hi - lo]
         parts.append(torch.view_as_complex(t) if pad.is_complex() else t)
-    return torch.cat(parts, dim=0)
+    full = torch.cat(parts, dim=0)
+    if not cyclic:
+        return full
+    # rank-major -> sweep order
+    order = np.concatenate([shard_indices(n_items, r, world, True) for r in range(world)])
+    inv = torch.as_tensor(np.argsort(order), device=full.device)
+    return full.index_select(0, inv)
 
 
 def asih_eps_table():
@@ -73,6 +91,34 @@ def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtyp
     return sim.S_parameters([list(o) for o in orders], direction=direction, port=port, polarization=polarization)
 
 
+# HBM footprint of one sweep point, in units of one n x n complex128 matrix (n = 2 (2 ox + 1)(2 oy + 1)): measured on MI355X with the caching
+# allocator -- single patterned layer, order [15,15], 128 points: 75.8 GB allocated / 111.8 GB reserved = 10.0 / 14.8 matrices per point; 4-layer stack
+# with the streaming cascade, order [21,21], 64 points: 228 / 247 GB = 16.3 / 17.6.  precision="native" halves the element.
+_POINT_MATRICES = {1: 15.0, 2: 18.0}          # layers == 1 / layers >= 2 (what the allocator RESERVES, which is what must fit)
+_HEADROOM = 0.10                               # fraction of the device memory a sweep leaves free
+
+
+def auto_chunk(B, order, n_layers, precision, device):
+    """Largest number of points solved in lock-step that fits the free HBM of `device` with _HEADROOM to spare (a multiple of 8 when it
+    is cut: the mixed-precision eigensolver and its iteration groups want batches of at least 8).  Raises with the numbers when not even
+    one point fits -- instead of an allocator error in the middle of a solve."""
+    if device.type != "cuda":
+        return B
+    n = 2 * (2 * order[0] + 1) * (2 * order[1] + 1)
+    per_point = _POINT_MATRICES[1 if n_layers <= 1 else 2] * n * n * (16 if precision == "high" else 8)
+    free, total = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the caching allocator's idle blocks are ours to reuse
+    budget = free - _HEADROOM * total
+    fit = int(budget // per_point)
+    if fit < 1:
+        raise RuntimeError("torcwa_amd sweep: one sweep point at order %s needs about %.1f GB of HBM (%d x %d complex matrices x %.0f), but only "
+                           "%.1f GB are free on %s (%.1f GB total, %.0f %% kept as headroom); free memory or lower the order"
+                           % (list(order), per_point / 1e9, n, n, _POINT_MATRICES[1 if n_layers <= 1 else 2], free / 1e9, device, total / 1e9, 100 * _HEADROOM))
+    if fit >= B:
+        return B
+    return fit if fit < 8 else fit - fit % 8
+
+
 def _slice(v, lo, hi, B):
     """Per-point quantities are [B] vectors or [B,nx,ny] grids; a 2-D tensor is a grid SHARED by all points and is never cut
     (a 128 x 128 grid in a 128-point sweep is not a per-point quantity)."""
@@ -91,7 +137,8 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
     B = freq.shape[0]
     eng = engine if engine is not None else default_engine()
     old_check, eng.check_info = eng.check_info, check_info         # restored below: the engine may be shared with other solvers
-    chunk = B if chunk is None else int(chunk)
+    # chunk=None: as many points in lock-step as the free HBM holds (the reference's per-point loop cannot run out of memory; neither must this)
+    chunk = auto_chunk(B, order, len(layers), precision, freq.device) if not chunk else int(chunk)
     if streams > 1 and chunk >= B:
         chunk = -(-B // streams)
     spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
@@ -144,9 +191,9 @@ def _run_spans(run, spans, streams, dev):
 def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
     """B sweep points of a 1-patterned-layer stack (configs 2 and 4 of BASELINE.json): freq [B], eps_grids [B,nx,ny].
 
-    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default: all of them).  At order [15,15]
-              (n = 1922) a point costs about 0.6 GB allocated / 0.8 GB reserved, so up to 256 points fit the 288 GB of an MI355X, and
-              larger chunks are faster (measured: 23.6 / 28.8 / 31.6 layer-solves/s at 64 / 128 / 256 points).
+    chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default None = as many as the free HBM holds with
+              10 % headroom, `auto_chunk`).  At order [15,15] (n = 1922) a point costs about 0.6 GB allocated / 0.9 GB reserved, so about 256 points
+              fit the 288 GB of an MI355X, and larger chunks are faster (measured: 23.6 / 28.8 / 31.6 layer-solves/s at 64 / 128 / 256 points).
     streams : number of HIP streams / host threads the chunks are dealt to (default 1: on MI355X one stream was measured
               faster -- the QR window kernel needs 133 KB of LDS and evicts the slab workgroups of the other stream).
     """
