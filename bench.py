@@ -62,7 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=4096, help="config 4: total sweep points (16^3 grid, cycled if larger)")
     ap.add_argument("--order", type=int, default=0, help="Fourier order [o,o]; 0 = the config's own: 15 (2, 4), 21 (3), 25 (5)")
     ap.add_argument("--grid", type=int, default=300, help="permittivity grid is grid x grid")
-    ap.add_argument("--chunk", type=int, default=0, help="points solved in lock-step (0 = min(local points, 128), config 4: min(local points, 256))")
+    ap.add_argument("--chunk", type=int, default=0, help="points solved in lock-step (0 = min(local points, 128); config 3: 64; config 4: what the sweep driver "
+                    "fits into the free HBM with 10 %% headroom, torcwa_amd.sweep.auto_chunk)")
+    ap.add_argument("--cyclic", action="store_true", help="config 4, N > 1: rank r solves points r, r + N, ... instead of a contiguous block (SURVEY.md 8(e))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -294,62 +296,123 @@ def layer_solve_roof(n, precision):
 
 # instrumented tags (torcwa_amd/csrc/prof.hip).  "gemm<N,N>" = one trx gemm() call with both operands untransposed: the large-tile kernel
 # gemm_big_kernel plus the narrow-tile launches that take its thin remainders, or one gemm_mfma_kernel launch for small / panel shapes.
-_BOUND = {"gemm<N,N>": "mfma", "gemm<other ops>": "mfma", "apply_window_kernel": "mfma", "hess_gemv_kernel": "hbm",
-          "invit_solve_kernel": "mfma",      # fp64 VECTOR FMAs: on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TF)
-          "gemm<N,N> fp32": "mfma", "gemm<other ops> fp32": "mfma"}
+_BOUND = {"gemm<N,N>": "mfma", "gemm<other ops>": "mfma", "apply_links_kernel<0>": "mfma", "apply_links_kernel<1>": "mfma", "hess_gemv_kernel": "hbm",
+          "gemm<N,N> fp32": "mfma", "gemm<other ops> fp32": "mfma",
+          "qr_window_kernel": "latency", "qr_prepare_kernel": "latency", "hess_col_kernel": "latency", "lu_panel_kernel": "latency"}
+# Latency-bound kernels (one wave / one workgroup per matrix walking a chain of dependent steps): the roof is the ISSUE-LIMITED time of the
+# chain -- what the dependent instructions of one step cost when nothing else waits -- in shader cycles per step (the models are stated here,
+# next to the measurement they are held against; the clock is the 2.4 GHz the matrix peaks are quoted at).  `achieved` = steps per second and
+# matrix, `peak` = clock / cycles_min, frac = t_min / t_measured of a launch.
+_CLOCK_HZ = 2.4e9
+_LATENCY_MODEL = {
+    # chain step of the bulge chase (qr_window_kernel, eig_qr.hip): rotation from two LDS operands (LDS round trip ~64 cycles + ~12 dependent
+    # VALU incl. one quarter-rate v_rsq: ~90) ; left phase (LDS read round trip, 8 FMAs, write: ~100) ; barrier ; right phase (~100) ; barrier
+    # (16 waves: ~30 each at best) => ~400 cycles.  Steps are counted on the device (chain steps per matrix).
+    "qr_window_kernel": dict(unit="chain steps/s per matrix", cycles_min=400.0, steps="device",
+                             model="rotation generate ~150 + left ~100 + right ~100 cycles + 2 barriers of a 16-wave workgroup ~50 = 400 cycles per chain step"),
+    # rotation of the explicit-shift QR of the AED window (qr_prepare_kernel: small_schur): v_readlane broadcast of (f, g), rotation generate
+    # (~90), own column pair update + LDS write + next row read (~64 + 20) => ~180 cycles; the right / U phases add ~1/3 (lanes independent).
+    "qr_prepare_kernel": dict(unit="rotations/s per matrix", cycles_min=240.0, steps="device",
+                              model="broadcast + rotation generate ~90 + column update and LDS round trip ~90 cycles per rotation of the left phase, + 1/3 for the lane-parallel right / U phases = 240"),
+    # one Householder column (hess_col_kernel): combine the partial sums (one global round trip ~2000 cycles under load), one combined reduction over
+    # the column (LDS tree, ~10 barriers x ~60), write reflector + T column (one more global round trip) => ~5000 cycles per column
+    "hess_col_kernel": dict(unit="columns/s per matrix", cycles_min=5000.0, steps=1.0,
+                            model="2 dependent global round trips (~2000 cycles each under load) + one block reduction (~10 barriers) per column = 5000 cycles"),
+    # one 32-column LU panel (lu_split_* launches, lu.hip): per column a pivot search (global column slice + two-level reduction ~2500 cycles) and a
+    # rank-1 update of the panel (one global round trip ~2000) as ONE launch (~5 us launch latency = 12000 cycles when the chain is launch-bound)
+    "lu_panel_kernel": dict(unit="panel columns/s per matrix", cycles_min=4500.0, steps=32.0,
+                            model="pivot search ~2500 + rank-1 panel update ~2000 cycles per column, 32 columns per panel (launch latency of the per-column launches NOT included in the minimum)"),
+}
 # kernels of a rocprofv3 trace that belong to a tag (prefixes of profiles/kernel_stats.py's short names), and the source files that define them
 # (a committed profile stays valid for a tag as long as THESE files are unchanged; other kernels may have moved on)
 _TRACE_KEYS = {"gemm<N,N>": ("gemm_big_kernel<0, 0", "gemm_mfma_kernel<double, 0, 0"), "gemm<N,N> fp32": ("gemm_mfma_kernel<float, 0, 0",),
-               "apply_window_kernel": ("apply_window_",), "hess_gemv_kernel": ("hess_gemv_kernel",), "qr_prepare_kernel": ("qr_prepare_kernel",),
-               "qr_window_kernel": ("qr_window_kernel",), "hess_col_kernel": ("hess_col_kernel",), "lu_panel_kernel": ("lu_panel_kernel",)}
-_TAG_SOURCES = {"gemm": ("gemm.hip", "gemm_big.hip", "mfma.hpp", "common.hpp", "acc_regs.hpp"), "apply": ("eig_qr.hip", "mfma.hpp", "common.hpp"),
+               "apply_links_kernel<0>": ("apply_links_kernel<float, 0", "apply_links_kernel<double, 0", "apply_links_kernel<float, 2", "apply_links_kernel<double, 2"),
+               "apply_links_kernel<1>": ("apply_links_kernel<float, 1", "apply_links_kernel<double, 1"),
+               "hess_gemv_kernel": ("hess_gemv_kernel",), "qr_prepare_kernel": ("qr_prepare_kernel",),
+               "qr_window_kernel": ("qr_window_kernel",), "hess_col_kernel": ("hess_col_kernel",), "lu_panel_kernel": ("lu_panel_kernel", "lu_split_")}
+_TAG_SOURCES = {"gemm": ("gemm.hip", "gemm_big.hip", "mfma.hpp", "common.hpp"), "apply": ("eig_qr.hip", "mfma.hpp", "common.hpp"),
                 "qr_": ("eig_qr.hip", "common.hpp"), "hess": ("eig_hess.hip", "common.hpp"), "lu_": ("lu.hip", "common.hpp")}
 # kernels of the eigensolver proper: with the mixed-precision route (libtrx default for complex128 input, n >= 256, batch >= 8) they run in fp32
-_EIG_STAGE = ("apply_window_kernel", "qr_prepare_kernel", "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel")
-
-
-_ROUTE_MEMORY = [False]        # set after the run: torcwa_amd.Engine recorded a mixed-route fallback for this size and switched the sweep to fp64
+_EIG_STAGE = ("apply_links_kernel<0>", "apply_links_kernel<1>", "qr_prepare_kernel", "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel")
 
 
 def eig_is_mixed(args, n, chunk):
-    return (args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
-            and not _ROUTE_MEMORY[0])
+    return args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
+
+
+def read_prof_tags(engine):
+    """{tag name: (launches, timed launches, flops of the timed, bytes of the timed, ms of the timed, flops over all launches)} for every tag
+    libtrx instruments (kernel tags and the wall-clock phase tags of trx_eig)."""
+    import ctypes
+    out = {}
+    for tag in range(64):
+        name = engine.lib.prof_tag_name(tag).decode()
+        if name == "?":
+            break
+        buf = (ctypes.c_double * 6)()
+        engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
+        out[name] = tuple(buf)
+    return out
+
+
+def phase_table(tags, py_phases, elapsed, steps):
+    """Wall-clock phases of a step: the Python-level brackets of torcwa_amd.Engine (event pairs on the compute stream around the library calls of a
+    layer-solve) and, inside trx_eig, the library's own phase brackets (balance / Hessenberg / QR from fork to join of its iteration groups /
+    Schur vectors / Newton refinement).  share = of the measured step."""
+    step_ms = 1e3 * elapsed / steps
+    rows = []
+    for name, ms in sorted(py_phases.items(), key=lambda kv: -kv[1]):
+        rows.append({"phase": name, "ms_per_step": ms / steps, "share_of_step": ms / steps / step_ms})
+    inner = []
+    for name, v in tags.items():
+        if name.startswith("phase:") and v[1] > 0:
+            ms = v[4] / v[1] * v[0]
+            inner.append({"phase": "trx_eig / " + name[6:], "ms_per_step": ms / steps, "share_of_step": ms / steps / step_ms, "calls_per_step": v[0] / steps})
+    inner.sort(key=lambda r: -r["ms_per_step"])
+    return {"step_ms": step_ms, "phases": rows, "inside_trx_eig": inner,
+            "note": "event-timed on the compute stream, summed over the timed steps / steps; phases are sequential on that stream, so shares add up to ~1 "
+                    "(the remainder is torch glue between the library calls)"}
 
 
 def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
     """Live figures from the HIP events libtrx recorded (on the launch streams, uniformly sampled) during the timed region."""
-    import ctypes
-    peak_tf = PEAK_TFLOPS[args.precision]
+    tags = read_prof_tags(engine)
     kernels = []
-    for tag in range(11):
-        buf = (ctypes.c_double * 6)()
-        engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
-        launches, timed, flops_t, bytes_t, ms, flops_all = list(buf)
-        if timed <= 0 or ms <= 0:          # not launched, or no usable event timing (CPU emulator)
+    for name, (launches, timed, flops_t, bytes_t, ms, flops_all) in tags.items():
+        if name.startswith("phase:") or timed <= 0 or ms <= 0:          # phases: see phase_table; not launched, or no usable event timing (CPU emulator)
             continue
-        name = engine.lib.prof_tag_name(tag).decode()
         fp32_kernel = name.endswith("fp32") or args.precision == "native" or (name in _EIG_STAGE and eig_is_mixed(args, n, chunk))
         peak_tf = PEAK_TFLOPS["native" if fp32_kernel else "high"]
         avg_us = 1e3 * ms / timed
         k = {"kernel": name, "launches": int(launches), "timed_launches": int(timed), "avg_us": avg_us, "arithmetic": "fp32" if fp32_kernel else "fp64",
              "est_total_ms_per_step": avg_us * launches / 1e3 / steps, "sum_over_wall": avg_us * launches / 1e6 / elapsed}
         bound = _BOUND.get(name)
-        if name == "apply_window_kernel" and flops_all > 0:
+        if name.startswith("apply_links_kernel") and flops_all > 0:
             # data-dependent work, counted on the device over ALL launches; time = uniform-sample average x launches
             k.update(bound="mfma", achieved=flops_all / (avg_us * 1e-6 * launches) / 1e12, peak=peak_tf, unit="TFLOP/s",
                      algorithmic_flops_per_launch=flops_all / launches,
-                     note="flops = 8 ww^2 (2n - ww) per matrix and window step; the iteration groups of the QR phase run this kernel "
-                          "concurrently on their own streams, so a launch's event time includes the share of the GPU the others take")
+                     note="flops = 8 ww^2 x (columns right of the band | rows above the window + n) per matrix and link (4M count; the banded product of a chase "
+                          "unitary issues 13/16 of them); the iteration groups of the QR phase run their kernels concurrently on their own streams, so a "
+                          "launch's event time includes the share of the GPU the others take")
         elif bound == "mfma" and flops_t > 0:
             k.update(bound="mfma", achieved=flops_t / (ms * 1e-3) / 1e12, peak=peak_tf, unit="TFLOP/s",
                      algorithmic_flops_per_launch=flops_t / timed, algorithmic_bytes_per_launch=bytes_t / timed)
         elif bound == "hbm" and bytes_t > 0:
             k.update(bound="hbm", achieved=bytes_t / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_launch=bytes_t / timed)
+        elif bound == "latency":
+            m = _LATENCY_MODEL[name]
+            steps_per_launch = (flops_all / launches) if m["steps"] == "device" else m["steps"]
+            if steps_per_launch <= 0:
+                continue
+            t_min_us = steps_per_launch * m["cycles_min"] / _CLOCK_HZ * 1e6
+            k.update(bound="latency", achieved=steps_per_launch / (avg_us * 1e-6), peak=_CLOCK_HZ / m["cycles_min"], unit=m["unit"],
+                     dependent_steps_per_launch=steps_per_launch, cycles_per_step_measured=avg_us * 1e-6 * _CLOCK_HZ / steps_per_launch,
+                     cycles_per_step_min=m["cycles_min"], t_min_us_per_launch=t_min_us, model=m["model"],
+                     note="latency-bound chain (one wave or workgroup per matrix): roof = issue-limited cycles of the dependent steps of one launch")
         else:
-            # one wave / one workgroup per matrix, dependent chain of small steps: no meaningful flop or byte rate
-            k.update(bound="hbm", achieved=0.0, peak=PEAK_HBM_GBS, unit="GB/s", note="latency-bound (one wave or workgroup per matrix)")
+            continue
         k["frac"] = k["achieved"] / k["peak"]
-        if name in ("apply_window_kernel", "gemm<N,N>", "gemm<other ops>") and not fp32_kernel and k["achieved"] > 0:
+        if name in ("gemm<N,N>", "gemm<other ops>") and not fp32_kernel and k["achieved"] > 0:
             # fp64 path: 3M complex product, three real MFMAs where the 8-flops-per-complex-MAC count has four
             k["issued_mfma_tflops"] = 0.75 * k["achieved"]
             k["issued_mfma_frac"] = 0.75 * k["frac"]
@@ -379,10 +442,14 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
                      "in fp64, the first stage of the mixed-precision eigensolver in fp32); the survey's own figure prices the same flops at the fp32 peak"
                      if args.precision == "high" else "fp32 (157.3 TF, 8-byte elements)"}
     dom["kernels"] = kernels
+    ph = phase_table(tags, engine.phase_report(), elapsed, steps)
+    dom["phases"] = ph
+    red = sum(r["share_of_step"] for r in ph["phases"] if r["phase"].startswith("Redheffer"))
+    dom["redheffer_share_of_step"] = red
     return dom
 
 
-PROFILE_TAG = "r04"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
+PROFILE_TAG = "r05"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
 
 
 def _tag_kernels(prof, name):
@@ -491,9 +558,11 @@ def main():
             dist.barrier()
         sync()
 
+    cyclic = bool(args.cyclic and args.config == 4)
+
     def local_block(total):
-        lo, hi = shard_range(total, rank, world)
-        return np.arange(lo, hi)
+        from torcwa_amd.sweep import shard_indices
+        return shard_indices(total, rank, world, cyclic=cyclic)
 
     def measure(idx, steps, warmup, profile):
         """W untimed + K timed steps over this rank's sweep points `idx`; returns (elapsed max over ranks, last result, inputs)."""
@@ -509,7 +578,11 @@ def main():
         # config 3: with the streaming cascade (one layer resident) 64 points of the 4-layer stack take 228 GB allocated / 247 GB reserved of
         # the 288 GB (3.96 vs 3.44 layer-solves/s in chunks of 32: 114 GB); a smaller device falls back to 32
         big = EMU or torch.cuda.get_device_properties(device).total_memory >= 280e9
-        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 64 if big else 32, 4: 256, 5: 1}[args.config]))
+        chunk = args.chunk if args.chunk > 0 else max(1, min(len(idx), {2: 128, 3: 64 if big else 32, 4: 1 << 30, 5: 1}[args.config]))
+        if args.config == 4 and args.chunk <= 0 and not EMU:
+            # config 4 goes through the public driver WITHOUT a chunk argument: the driver sizes it from the free HBM (the figure is reported)
+            from torcwa_amd.sweep import auto_chunk
+            chunk = auto_chunk(len(idx), order, 1, args.precision, device)
         # (round 3 forced the all-fp64 route here: the mixed route's extra n^2 buffer did not fit at chunk 64; the refinement now builds its
         # update matrix in place, so the library default applies -- to be confirmed by the config-3 run)
         out = None
@@ -531,6 +604,8 @@ def main():
         if profile:
             engine.lib.prof_reset()
             engine.lib.prof_enable(0 if os.environ.get("TRX_BENCH_NOPROF") == "1" else 1)
+            engine.phase_report()                                                       # drop the warm-up's brackets
+            engine.profile_phases = os.environ.get("TRX_BENCH_NOPROF") != "1"
             if not EMU:
                 mstat["timed0"] = torch.cuda.memory_stats(device)
         t0 = time.perf_counter()
@@ -539,6 +614,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         engine.lib.prof_enable(0)
+        engine.profile_phases = False
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -561,7 +637,6 @@ def main():
     n_fail = engine.failures()
     if n_fail:
         raise SystemExit(f"bench invalid: {n_fail} numerical failures (info != 0) inside the timed region")
-    _ROUTE_MEMORY[0] = bool(getattr(engine, "_eig_route_hint", None))
     roof = roofline(engine, args, elapsed, args.steps, n, len(idx) * layers_per_point, chunk) if rank == 0 else None
     if args.host_profile and rank == 0:
         import cProfile
@@ -572,7 +647,7 @@ def main():
         sync()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
-    full = gather_sweep(out, total) if world > 1 else out                 # the one collective of the job (RCCL all_gather, KB-sized)
+    full = gather_sweep(out, total, cyclic=cyclic and scaling != "weak") if world > 1 else out      # the one collective of the job (RCCL all_gather, KB-sized)
     value = total * layers_per_point * args.steps / elapsed
 
     # ---- strong-scaling leg (north_star: ">= 6x strong scaling of a wavelength sweep at 8 GPUs") ------------------------------
@@ -613,11 +688,11 @@ def main():
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
                        "chunk": int(chunk), "streams": args.streams,
-                       "eig_route": ("mixed: fp32 eigendecomposition + fp64 Newton refinement" if eig_is_mixed(args, n, chunk) else
-                                     ("fp64 (Hessenberg, multi-shift QR, Schur vectors)" +
-                                      (" -- chosen by the engine's route memory after the mixed route fell back on this sweep (clusters of close "
-                                       "eigenvalues beyond the refinement's exact treatment)" if _ROUTE_MEMORY[0] else "")))
+                       "eig_route": ("mixed: fp32 eigendecomposition + fp64 Newton refinement; matrices the refinement cannot certify are redone in fp64 "
+                                     "inside trx_eig (last call of the run: %d of %d)" % (int(getattr(engine, "last_eig_fallback", 0)), int(chunk))
+                                     if eig_is_mixed(args, n, chunk) else "fp64 (Hessenberg, multi-shift QR, Schur vectors)")
                                     if args.precision == "high" else "fp32 (Hessenberg, multi-shift QR, Schur vectors)",
+                       "sharding": ("cyclic (rank r: points r, r + N, ...)" if cyclic else "contiguous blocks") if world > 1 else None,
                        "precision": args.precision, "backend": ("gloo" if EMU else "nccl (RCCL)") if world > 1 else None},
             "txx00_sample": [float(full[0, 0].real), float(full[0, 0].imag)], "gathered_points": int(full.shape[0]),
             "numerical_failures": 0, "hbm": mem, "csrc_sha16": csrc_sha16(),
@@ -630,6 +705,10 @@ def main():
         if strong is not None:
             res["strong_scaling"] = strong
         res["roofline"] = roof
+        if EMU:
+            # the CPU kernel-logic emulator is a launcher-plumbing test: it must never look like a measurement
+            res["emulator_plumbing"] = {"units_per_s": res["value"], "ms_per_step": res["ms_per_step"]}
+            res["value"], res["ms_per_step"], res["roofline"] = None, None, None
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             model, phys, logical = host_cpu()
             threads = args.cpu_threads if args.cpu_threads > 0 else phys

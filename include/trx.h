@@ -99,26 +99,21 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       followed by a sweep in the same outer iteration; 0 switches that sweep off.  No automatic value.
  *   "qr_moves"    0-64  LITERAL bound, default 12 (TRX_QR_MOVES): undeflatable eigenvalues an AED moves out of the way; 0 = no reordering.
  *   "qr_rotb"     1 = the in-LDS Schur solver of the AED broadcasts each rotation with ds_bpermute (round-3 code); default: v_readlane (TRX_QR_ROTB)
- *   "slab_spw"    1, 2, 4  strips per wave of the off-window update with static strips (TRX_SLAB_SPW)     auto: 4 (batch >= 64), else 2
- *   "slab_dyn"    1 static / 2 dynamically claimed strips (TRX_SLAB_DYN)              auto: dynamic for groups of >= 16 matrices
- *   "slab_wgs"    32-4096 workgroups per dynamic off-window launch (TRX_SLAB_WGS)     auto: 512
- *   "slab_pipe"   2 = software-pipelined off-window kernel (TRX_SLAB_PIPE)            auto: off (measured slower)
- *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chain unitary
+ *   "qr_super"    1-8   window steps per launch of the chase kernel (fp32, one chain per sweep: TRX_QR_SUPER)     auto: 4.  The workgroup applies each
+ *                       window's unitary itself to the band of columns the next windows slide over; the left update beyond the band is one
+ *                       launch per super-step, the right update of H and the update of Z one launch per sweep (link log of the sweep)
+ *   "slab_spw"    1, 2, 4  strips per wave of the left update (TRX_SLAB_SPW)           auto: 1
+ *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chase unitary
  *   Eigenvector route of trx_eig
- *   "eig_vec"     1 = all-fp64 pipeline with Schur vectors, 2 = inverse iteration on the Hessenberg matrix behind an eigenvalues-only QR
- *                       phase, 3 = mixed precision: fp32 eigendecomposition refined to fp64 by Newton steps (TRX_EIG_VEC)
+ *   "eig_vec"     1 = all-fp64 pipeline (all-fp32 for complex64 input) with Schur vectors, 3 = mixed precision wherever n >= 8: fp32
+ *                       eigendecomposition refined to fp64 by Newton steps (TRX_EIG_VEC)
  *                       auto: mixed precision for complex128 input of n >= 256 AND batch >= 8, else Schur vectors; trx_eig_ws_bytes depends on
- *                       this knob (per call and race-free: trx_eig_opts)
+ *                       this knob (per call and race-free: trx_eig_opts).  (2, inverse iteration on the Hessenberg matrix, was removed in round 5.)
  *   "eig_refine"  1-4   Newton steps of the mixed-precision route; 0 = default (2: the accuracy class of the all-fp64 pipeline; one step
- *                       leaves an eigen-residual of ~5e-12 ||A||, which is what torcwa_amd asks for on behalf of complex64 problems)
- *   "invit_cfg"   0-6   layout of the inverse-iteration kernel (TRX_INVIT_CFG): 0/1 512 threads, register prefetch 2 deep; 2: 3 deep;
- *                       3: 1 deep; 4: 1024 threads; 5 / 6: 1024 / 512 threads with the direct-to-LDS column ring
- *   "invit_ring"  1-3 (register variants) or 3-4 (ring variants) columns of H resident in LDS;  "invit_wpl" 1, 2, 4, 8: minimum waves
- *                       per eigenvalue (tests);  "invit_xcd" 1 = plain 2-D grid instead of the XCD-aware launches
+ *                       leaves an eigen-residual of ~5e-12 ||A||)
  *   GEMM (trx_gemm and every product inside the library)
- *   "gemm_big"    large-tile complex128 kernel for outputs of at least 2 x 2 of its tiles and k >= 64 (TRX_GEMM_BIG): 1 = 96 x 96 and 2 = 128 x 80
- *                       with one wave per SIMD, 3 = 128 x 96 with 8 waves, 4 = off (64 x 64 tile)                    auto: 3
- *   "gemm_dma"    1 = the 64 x 64 tile through a direct-to-LDS operand ring (TRX_GEMM_DMA)                          auto: off (measured equal)
+ *   "gemm_big"    4 = large-tile complex128 kernel (128 x 96 on 8 waves; outputs of at least 2 x 2 tiles, k >= 64) OFF: the 64 x 64 tile everywhere
+ *                       (TRX_GEMM_BIG)                                                                              auto: on
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch

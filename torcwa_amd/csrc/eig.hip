@@ -4,6 +4,7 @@
 // Hessenberg reduction (eig_hess.hip) -> multi-shift QR to Schur form (eig_qr.hip) -> triangular eigenvectors + back-transform
 // + undo of the balancing + unit-norm scaling (eig_vec.hip).
 #include "eig.hpp"
+#include "prof.hpp"
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -55,7 +56,7 @@ static size_t mixed_extra_bytes(int n, int batch) {
     const size_t zx = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
     size_t tot = 0;
     if (pool > zx) tot += al256(pool - zx);                                    // spill of the fp32 pool beyond Z | X
-    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(REFINE_CLUSTER_BYTES * B) + al256(e * B * N);
+    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(8 * 64 * B) + al256(REFINE_CLUSTER_BYTES * B) + al256(e * B * N);
     return tot;
 }
 
@@ -78,7 +79,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * EigPlan::QKC * EigPlan::QNS);                // shifts
     tot += al256(sizeof(T) * B * N) + al256(sizeof(T) * 3 * B * N) + al256(sizeof(int) * 2 * B);   // balancing: D, scratch, flags
     tot += al256(sizeof(QrState) * B);
-    tot += al256(sizeof(int) * 64 + sizeof(long long) * 24);
+    tot += al256(sizeof(int) * 128 + sizeof(long long) * 24);
     if (eig_uses_mixed(n, batch, sizeof(T))) tot += mixed_extra_bytes(n, batch);
     return tot;
 }
@@ -121,9 +122,9 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.bal_w = (T*)take(sizeof(T) * 3 * B * N);
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
-    Bf.summary = (int*)take(sizeof(int) * 64 + sizeof(long long) * 24);   // up to 8 iteration groups x 8 ints
+    Bf.summary = (int*)take(sizeof(int) * 128 + sizeof(long long) * 24);  // up to 8 iteration groups x 16 ints
     Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = nullptr;
-    Bf.r_eoff = Bf.r_lmax = nullptr;
+    Bf.r_eoff = Bf.r_lmax = Bf.r_scan = nullptr;
     Bf.r_pairX = nullptr;
     Bf.r_d0 = nullptr;
     if (eig_uses_mixed(n, batch, sizeof(T))) {
@@ -133,6 +134,7 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
         Bf.r_flags = (int*)take(sizeof(int) * (B + 1));
         Bf.r_eoff = (T*)take(8 * B);
         Bf.r_lmax = (T*)take(8 * B);
+        Bf.r_scan = (T*)take(8 * 64 * B);
         Bf.r_pairX = (cx<T>*)take(REFINE_CLUSTER_BYTES * B);
         Bf.r_d0 = (cx<T>*)take(e * B * N);
     }
@@ -220,7 +222,9 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
     EigBuffers<T> B;
     eig_carve<T>(B, A, ws, n, batch);
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-    int rc = balance<T>(s, B, n, batch);          // A <- D^-1 A D (zgebal 'S'); undone on the eigenvectors in schur_vectors
+    int rc;
+    { ProfScope ph(PROF_PH_BALANCE, s, 0, 0);
+      rc = balance<T>(s, B, n, batch); }       // A <- D^-1 A D (zgebal 'S'); undone on the eigenvectors in schur_vectors
     if (rc) return rc;
     if constexpr (sizeof(T) == 8) {
         if (eig_uses_mixed(n, batch, sizeof(T))) {
@@ -237,12 +241,13 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32, eig_ws_bytes_f32(n, batch));      // its info reaches eig_refine in R.linfo and is folded into the flags there
             if (rc) return rc;
             RefineBuffers<T> R;
-            R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax;
+            R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax; R.scan_part = B.r_scan;
             R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
             int any = 0;
             std::vector<int> bad(batch, 0);
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
-            rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any, bad.data());
+            { ProfScope ph(PROF_PH_REFINE, s, 0, 0);
+              rc = eig_refine<T>(s, R, (const cx<T>*)A, V32, w32, (cx<T>*)w, (cx<T>*)V, n, batch, tl_refine > 0 ? tl_refine : refine_steps(), &any, bad.data()); }
             if (rc) return rc;
             tl_last_fallback = any;
             if (!any) return finish_vectors<T>(s, B, n, batch, (cx<T>*)V);
@@ -263,13 +268,17 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
 
 template <class T>
 int eig_after_balance(hipStream_t s, const EigBuffers<T>& B, void* w, void* V, int n, int batch, int* info) {
-    int rc = hessenberg<T>(s, B, n, batch);
-    if (rc) return rc;
-    TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n);
+    int rc;
+    { ProfScope ph(PROF_PH_HESSENBERG, s, 0, 0);
+      rc = hessenberg<T>(s, B, n, batch);
+      if (rc) return rc;
+      TRX_LAUNCH((clear_below_subdiag_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n); }
     // Schur vectors: T = Z^H H Z with Z accumulated, eigenvectors of T by blocked back-substitution, back-transform.  (An eigenvalues-only
     // QR phase + inverse iteration on H was built in round 3, lost at every batch size -- profiles/r03_invit_route.txt -- and was removed.)
-    rc = hessenberg_qr<T>(s, B, n, batch, info);
+    { ProfScope ph(PROF_PH_QR, s, 0, 0);
+      rc = hessenberg_qr<T>(s, B, n, batch, info); }
     if (rc) return rc;
+    ProfScope ph(PROF_PH_VECTORS, s, 0, 0);
     return schur_vectors<T>(s, B, n, batch, (cx<T>*)w, (cx<T>*)V);
 }
 }  // namespace

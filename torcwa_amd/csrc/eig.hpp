@@ -60,12 +60,12 @@ struct EigBuffers {
     T* bal_w;      // [2,B,n] balancing scratch: row norms, column norms (sized for 3)
     int* bal_flags; // [B] per-matrix "needs balancing" flags (sized for 2B)
     QrState* st;   // [B]
-    int* summary;  // [64]: 8 ints per iteration group of the QR phase (up to 8 groups)
+    int* summary;  // [128]: 16 ints per iteration group of the QR phase (up to 8 groups)
     // mixed-precision route (fp64 only; null otherwise)
     char* mixed_pool;          // fp32 pool = Z | X | spill
     size_t mixed_pool_bytes;
     int *r_piv, *r_linfo, *r_flags, *r_partner;
-    T *r_eoff, *r_lmax;
+    T *r_eoff, *r_lmax, *r_scan;
     cx<T>* r_pairX;
     cx<T>* r_d0;               // [B,n] diagonal of G
 };
@@ -81,6 +81,7 @@ struct RefineBuffers {
     int* flags;      // [B + 1]  per matrix: 1 = off-diagonal part not small, 2 = a cluster the exact treatment does not take; [B] = any flag or LU failure
     T* eoff;         // [B] max off-diagonal |G_ij|
     T* lmax;         // [B] max |G_ii|
+    T* scan_part;    // [B, 2 * 32] partial maxima of the scan (its workgroups per matrix)
     int* partner;    // [B,n]
     cx<T>* pairX;    // [B] cluster tables (RefineClusters<T>, REFINE_CLUSTER_BYTES each)
     int* clus;       // [B,n]  256 * cluster + position, or -1 (aliases piv: the pivots are dead once the step's solve is done)

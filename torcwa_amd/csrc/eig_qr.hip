@@ -109,13 +109,13 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
 // BC: the inputs (f, g) of rotation r are broadcast from lane r with v_readlane and EVERY lane generates the rotation, instead of lane r
 // generating it and five ds_bpermute shuffles distributing the result (one LDS round trip less on the chain of every rotation).
 template <class T, bool BC = false>
-__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr) {
+__device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int SLD, long long* dbg = nullptr, int* nrot_out = nullptr) {
     const auto sync = [] { __syncthreads(); };
     const int lane = threadIdx.x;
     long long t_left = 0, t_right = 0, t_u = 0, t_pre = 0, tt = 0, n_it = 0, n_rot = 0;
     if (dbg) tt = clock64();
     const T ulp = eps_of<T>::value;
-    int ihi = m - 1, its = 0, total = 0;
+    int ihi = m - 1, its = 0, total = 0, nrot = 0;
     while (ihi > 0) {
         // deflation: flush negligible subdiagonals of [1, ihi] to zero, find the active block [l, ihi]
         int small = 0;
@@ -131,7 +131,8 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         sync();
         if (l == ihi) { --ihi; its = 0; continue; }
         ++its; ++total;
-        if (total > 40 * m) return false;
+        if (total > 40 * m) { if (nrot_out) *nrot_out = nrot; return false; }
+        nrot += ihi - l;
         cx<T> sig;
         {
             const cx<T> a = Hs[(ihi - 1) * SLD + ihi - 1], bq = Hs[(ihi - 1) * SLD + ihi], cq = Hs[ihi * SLD + ihi - 1], d = Hs[ihi * SLD + ihi];
@@ -217,6 +218,7 @@ __device__ bool small_schur(cx<T>* Hs, int m, cx<T>* Us, Rot<T>* rots, const int
         sync();
     }
     if (dbg && lane == 0) { dbg[0] += t_pre; dbg[1] += t_left; dbg[2] += t_right; dbg[3] += t_u; dbg[4] += n_it; dbg[5] += n_rot; }
+    if (nrot_out) *nrot_out = nrot;
     return true;
 }
 
@@ -342,7 +344,7 @@ template <class T, bool BC>
 __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ stall_,
                                                         cx<T>* __restrict__ Uall, cx<T>* __restrict__ shifts_all,
                                                         int* __restrict__ summary, int max_sweeps, int aed_w, int nibble, int aed_moves, int par, int max_chains,
-                                                        int sm, long long* dbg_all = nullptr) {
+                                                        int sm, int* __restrict__ counters, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (dbg_all && blockIdx.x == 0) ? dbg_all : nullptr;       // cycle counters of matrix 0 (TRX_QR_DEBUG)
     long long tk0 = dbg ? clock64() : 0;
@@ -422,7 +424,9 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
             Us[r * SLD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
         }
         __syncthreads();
-        const bool ok = small_schur<T, BC>(Hs, m, Us, rots, SLD);
+        int nrot = 0;
+        const bool ok = small_schur<T, BC>(Hs, m, Us, rots, SLD, nullptr, &nrot);
+        if (lane == 0) atomicAdd(&counters[1], nrot);           // dependent rotations of the in-LDS Schur solver (latency model of bench.py)
         __syncthreads();
         cx<T>* U = Uall + (long)b * QW * QW;                  // the unitary of a finished block / AED window (a DENSE link of the next sweep)
         for (int e = lane; e < m * m; e += 64) {
@@ -457,7 +461,9 @@ __global__ __launch_bounds__(64) void qr_prepare_kernel(cx<T>* __restrict__ Aall
     }
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[6] += t1 - tk0; tk0 = t1; }       // scans + window load
-    const bool okw = small_schur<T, BC>(Hs, nw, Us, rots, SLD, dbg);
+    int nrot = 0;
+    const bool okw = small_schur<T, BC>(Hs, nw, Us, rots, SLD, dbg, &nrot);
+    if (lane == 0) atomicAdd(&counters[1], nrot);
     __syncthreads();
     if (dbg && lane == 0) { const long long t1 = clock64(); dbg[7] += t1 - tk0; tk0 = t1; }       // Schur total
     int ns = nw;
@@ -988,7 +994,7 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
 template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
-                                                        int par, int nslot, int kc, int slot0, int nsteps, int band_on, long long* dbg_all = nullptr) {
+                                                        int par, int nslot, int kc, int slot0, int nsteps, int band_on, int* __restrict__ counters, long long* dbg_all = nullptr) {
     TRX_DYN_SMEM(smem);
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
     long long tk0 = dbg ? clock64() : 0;
@@ -1217,6 +1223,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
                 band_left_strip<T>(Ur, Ui, d, n, w0, ww, t & 63, band);
             }
         }
+        if (t == 0) atomicAdd(&counters[0], tau_end - tau0 + 1);      // chain steps of this matrix (latency model of bench.py)
         tau_cur = tau_end + 1;
         if (dbg) { dbg[14] += clock64() - tk0; tk0 = clock64(); }
         if (s + 1 < nsteps) __syncthreads();         // window write-back + band update visible to the next step's loads; LDS free again
@@ -1499,7 +1506,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     }
     if (attr_rc) return TRX_ERR_LAUNCH;
     TRX_LAUNCH((qr_init_kernel<T>), dim3(batch), dim3(64), 0, s, B.st, n);
-    if (hipMemsetAsync(B.summary, 0, sizeof(int) * 64, s) != hipSuccess) return TRX_ERR_LAUNCH;
+    if (hipMemsetAsync(B.summary, 0, sizeof(int) * 128, s) != hipSuccess) return TRX_ERR_LAUNCH;
     const int max_sweeps = 30 * n + 100;
     // strips per wave of the per-step left update: small batches are latency bound and keep the shorter per-launch chain
     const int spw = K.spw ? K.spw : 1;          // measured: 1 is best at every batch size (32.9 vs 32.4 layer-solves/s at batch 128 with 2)
@@ -1524,10 +1531,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         QrLane lane;           // streams + events
         hipStream_t s;
         int b0, nb;
-        int* summary;          // device, 8 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
-                               // per-step / the deferred updates (cumulative, in units of 4096 complex MACs)
+        int* summary;          // device, 16 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
+                               // per-step / the deferred updates (cumulative, in units of 4096 complex MACs); [8] chain steps of the window kernel, [9] rotations of the AED's Schur solver
         bool done;
-        unsigned work[2];
+        unsigned work[4];
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
@@ -1549,11 +1556,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         // group runs alone; interleaved, every group sees the same mix.  State, U and shift slots stay group-contiguous (b0).
         G.nb = (batch - g + ngroups - 1) / ngroups;
         G.b0 = g == 0 ? 0 : grp[g - 1].b0 + grp[g - 1].nb;
-        G.summary = B.summary + 8 * g;
+        G.summary = B.summary + 16 * g;
         G.done = false;
         G.issued = 0;
         G.read = 0;
-        G.work[0] = G.work[1] = 0;
+        G.work[0] = G.work[1] = G.work[2] = G.work[3] = 0;
         G.par = 0;
         G.g = g;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
@@ -1570,7 +1577,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // part.  Here the AED is, so every AED that leaves an active block is followed by a sweep in the same iteration.
     const int nibble = K.nibble, aed_moves = K.moves;
     const bool qr_debug = K.debug;                                        // cycle breakdown of the prepare / window kernels (matrix 0) to stderr
-    long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 64);    // 24 counters behind the group summaries
+    long long* dbg_dev = reinterpret_cast<long long*>(B.summary + 128);   // 24 counters behind the group summaries
     // One outer iteration of a group = the window steps of its sweep followed by the next prepare (deflation scan, AED, shifts)
     // and the copy of that prepare's 12-byte summary into pinned host memory.  The host runs ONE ITERATION AHEAD of what it has
     // read: iteration k+1 is queued with a step count from summary k-1 -- summary[1] is an upper bound (ihi + 1) for every block
@@ -1582,11 +1589,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         { ProfScope prof(PROF_QR_PREPARE, G.s, 0, 0);
           if (K.rotb == 1)
               TRX_LAUNCH((qr_prepare_kernel<T, false>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QW * QW,
-                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, G.summary + 8,
                          (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr);
           else
               TRX_LAUNCH((qr_prepare_kernel<T, true>), dim3(G.nb), dim3(64), smp, G.s, B.A + (long)G.g * n * n, mstride, n, B.st + G.b0, B.U + (long)G.b0 * QW * QW,
-                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w,
+                         B.shifts + (long)G.b0 * QKC * QNS, sum, max_sweeps, aed_w, nibble, aed_moves, G.par, kc, aed_w, G.summary + 8,
                          (qr_debug && G.b0 == 0) ? dbg_dev : (long long*)nullptr); }
         if (hipMemcpyAsync(G.lane.hsum + 4 * slot, sum, sizeof(int) * 3, hipMemcpyDeviceToHost, G.s) != hipSuccess) return false;
         return hipEventRecord(G.lane.evs[slot], G.s) == hipSuccess;
@@ -1610,8 +1617,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         for (int q = 0; q < nwin;) {
             const int ns = q == 0 ? 1 : (nwin - q < super ? nwin - q : super);
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, (long long*)nullptr); }
+              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbg_dev);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, (long long*)nullptr); }
             G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
               if (q == 0) {      // the dense link of slot 0, if there is one: left | right-H | Z, up to 3 n / 16 + 3 strips
@@ -1683,12 +1690,13 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (gmin >= 0 && hipEventSynchronize(grp[gmin].lane.evs[grp[gmin].read & 1]) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
     (void)hipGetLastError();          // hipEventQuery leaves hipErrorNotReady as the thread's last error
-    double work[2] = {0, 0};
+    double work[4] = {0, 0, 0, 0};
     for (int g = 0; g < nlanes; ++g) {
         Group& G = grp[g];
         if (!rc && prof_enabled() && hipMemcpyAsync(&G.work[0], G.summary + 3, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess &&
-            hipMemcpyAsync(&G.work[1], G.summary + 7, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess) {
-            work[0] += G.work[0]; work[1] += G.work[1];
+            hipMemcpyAsync(&G.work[1], G.summary + 7, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess &&
+            hipMemcpyAsync(&G.work[2], G.summary + 8, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess) {
+            for (int i = 0; i < 4; ++i) work[i] += G.work[i];
         }
         if (g > 0) {
             // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
@@ -1714,6 +1722,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     if (prof_enabled()) {      // algorithmic work of the update kernels: 8 flops per complex MAC, every element of a 64-wide slab read and written once
         prof_add_work(PROF_QR_APPLY_LEFT, 8.0 * 4096.0 * work[0], 2.0 * sizeof(cx<T>) * 4096.0 * work[0] / QW);
         prof_add_work(PROF_QR_APPLY_RIGHT, 8.0 * 4096.0 * work[1], 2.0 * sizeof(cx<T>) * 4096.0 * work[1] / QW);
+        // latency kernels: dependent steps per MATRIX (the matrices of a launch run side by side): chain steps / rotations summed over all matrices / batch
+        prof_add_work(PROF_QR_WINDOW, work[2] / batch, 0.0);
+        prof_add_work(PROF_QR_PREPARE, work[3] / batch, 0.0);
     }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch, ngroups);
     TRX_CHECK_LAUNCH();

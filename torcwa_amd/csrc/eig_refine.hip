@@ -34,14 +34,17 @@ __global__ __launch_bounds__(256) void cvt_kernel(const cx<TI>* __restrict__ in,
     if (i < count) { const cx<TI> v = in[i]; out[i] = cx<TO>((TO)v.x, (TO)v.y); }
 }
 
-// eoff[b] = max off-diagonal |G_ij| (abs1), lmax[b] = max |G_ii|;  lam[b, i] = d0[b, i] = G_ii
+// eoff[b] = max off-diagonal |G_ij| (abs1), lmax[b] = max |G_ii|;  lam[b, i] = d0[b, i] = G_ii.  RSPLIT workgroups per matrix (a row range
+// each: one workgroup per matrix read its 59 MB alone, 8 ms per call at the bench shape) leave partial maxima, refine_scan_reduce_kernel combines them.
+constexpr int RSPLIT = 32;
 template <class T>
-__global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, cx<T>* __restrict__ d0, T* __restrict__ eoff, T* __restrict__ lmax) {
+__global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restrict__ Gall, int n, cx<T>* __restrict__ lam, cx<T>* __restrict__ d0, T* __restrict__ part) {
     __shared__ T red[2][4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, sp = blockIdx.x;
     const cx<T>* G = Gall + (long)b * n * n;
+    const int r0 = (int)((long)n * sp / RSPLIT), r1 = (int)((long)n * (sp + 1) / RSPLIT);
     T eo = T(0), lm = T(0);
-    for (long e = threadIdx.x; e < (long)n * n; e += blockDim.x) {
+    for (long e = (long)r0 * n + threadIdx.x; e < (long)r1 * n; e += blockDim.x) {
         const int i = (int)(e / n), j = (int)(e - (long)i * n);
         const T a = abs1(G[e]);
         if (i == j) { lam[(long)b * n + i] = G[e]; d0[(long)b * n + i] = G[e]; lm = a > lm ? a : lm; }
@@ -56,8 +59,21 @@ __global__ __launch_bounds__(256) void refine_scan_kernel(const cx<T>* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) { eo = (red[0][w] > eo || !(red[0][w] == red[0][w])) ? red[0][w] : eo; lm = red[1][w] > lm ? red[1][w] : lm; }
-        eoff[b] = eo; lmax[b] = lm;
+        part[((long)b * RSPLIT + sp) * 2] = eo; part[((long)b * RSPLIT + sp) * 2 + 1] = lm;
     }
+}
+template <class T>
+__global__ void refine_scan_reduce_kernel(const T* __restrict__ part, T* __restrict__ eoff, T* __restrict__ lmax, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    T eo = T(0), lm = T(0);
+    for (int sp = 0; sp < RSPLIT; ++sp) {
+        const T e = part[((long)b * RSPLIT + sp) * 2], l = part[((long)b * RSPLIT + sp) * 2 + 1];
+        eo = (e > eo || !(e == e)) ? e : eo;
+        if (!(eo == eo)) break;                                       // NaN: final
+        lm = l > lm ? l : lm;
+    }
+    eoff[b] = eo; lmax[b] = lm;
 }
 
 // Which pairs (i, j) can NOT take the first-order formula: those whose coupling is not small against their gap,
@@ -412,7 +428,8 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         rc = lu_factor<T>(s, Vn, n, nn, n, R.piv, batch, R.linfo); if (rc) return rc;
         rc = lu_solve<T>(s, Vn, n, nn, n, R.piv, R.G, n, nn, n, batch); if (rc) return rc;
         TRX_LAUNCH(refine_fold_info_kernel, dim3(cdiv_i(batch, 64)), dim3(64), 0, s, R.flags, (const int*)R.linfo, batch);      // a singular V of THIS step: the next LU overwrites linfo
-        TRX_LAUNCH((refine_scan_kernel<T>), dim3(batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.d0, R.eoff, R.lmax);
+        TRX_LAUNCH((refine_scan_kernel<T>), dim3(RSPLIT, batch), dim3(256), 0, s, (const cx<T>*)R.G, n, w, R.d0, R.scan_part);
+        TRX_LAUNCH((refine_scan_reduce_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const T*)R.scan_part, R.eoff, R.lmax, batch);
         TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<T>*)R.G, (const cx<T>*)w, n, (const T*)R.eoff, (const T*)R.lmax, R.partner, R.flags);
         TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), 0, s, (const cx<T>*)R.G, n, w, (const int*)R.partner, R.clus, (RefineClusters<T>*)R.pairX, R.flags);
         if (it == 0 && steps > 1) {

@@ -112,6 +112,7 @@ extern "C" int trx_prof_get(int tag, double* out) {
 extern "C" const char* trx_prof_tag_name(int tag) {
     static const char* names[PROF_NTAGS] = {"gemm<N,N>", "gemm<other ops>", "qr_prepare_kernel", "apply_links_kernel<1>",
                                             "qr_window_kernel", "hess_gemv_kernel", "hess_col_kernel", "lu_panel_kernel", "apply_links_kernel<0>",
-                                            "gemm<N,N> fp32", "gemm<other ops> fp32"};
+                                            "gemm<N,N> fp32", "gemm<other ops> fp32",
+                                            "phase:balance", "phase:hessenberg", "phase:qr", "phase:schur_vectors", "phase:refinement"};
     return (tag >= 0 && tag < PROF_NTAGS) ? names[tag] : "?";
 }

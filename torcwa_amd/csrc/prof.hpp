@@ -6,7 +6,9 @@
 
 namespace trx {
 enum ProfTag { PROF_GEMM_NN = 0, PROF_GEMM_OTHER = 1, PROF_QR_PREPARE = 2, PROF_QR_APPLY_RIGHT = 3, PROF_QR_WINDOW = 4,
-               PROF_HESS_GEMV = 5, PROF_HESS_COL = 6, PROF_LU_PANEL = 7, PROF_QR_APPLY_LEFT = 8, PROF_GEMM_NN_F32 = 9, PROF_GEMM_OTHER_F32 = 10, PROF_NTAGS = 11 };      // the fp32 GEMMs (first stage of the
+               PROF_HESS_GEMV = 5, PROF_HESS_COL = 6, PROF_LU_PANEL = 7, PROF_QR_APPLY_LEFT = 8, PROF_GEMM_NN_F32 = 9, PROF_GEMM_OTHER_F32 = 10,
+               // wall-clock PHASES of trx_eig (one event pair per call on the caller's stream; the QR phase from fork to join of its iteration groups)
+               PROF_PH_BALANCE = 11, PROF_PH_HESSENBERG = 12, PROF_PH_QR = 13, PROF_PH_VECTORS = 14, PROF_PH_REFINE = 15, PROF_NTAGS = 16 };      // the fp32 GEMMs (first stage of the
                // mixed-precision eigensolver, precision="native") are counted apart from the fp64 ones: other peak, other roofline
 
 bool prof_enabled();

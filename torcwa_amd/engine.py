@@ -21,6 +21,25 @@ class NumericalError(RuntimeError):
     pass
 
 
+def _phase(name):
+    """Wall-clock bracket of an Engine method for the per-phase table of bench.py: when `engine.profile_phases` is on, a pair of HIP events
+    is recorded on the current stream around the call (no synchronisation; Engine.phase_report() reads them after the timed region)."""
+    def deco(fn):
+        def wrapped(self, *a, **kw):
+            if not self.profile_phases or self.device.type != "cuda":
+                return fn(self, *a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            try:
+                return fn(self, *a, **kw)
+            finally:
+                e1.record(torch.cuda.current_stream(self.device))
+                self._phase_events.append((name, e0, e1))
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 class Engine:
     def __init__(self, lib=None, device=None):
         if lib is None:
@@ -36,6 +55,19 @@ class Engine:
         self.check_info = True
         self._fail_acc = {}            # per host thread: device-side count of non-zero info entries seen while check_info is False
         self.last_eig_fallback = 0
+        self.profile_phases = False    # bench.py: event pairs around the phases of a layer-solve (see _phase)
+        self._phase_events = []
+
+    def phase_report(self, reset=True):
+        """{phase: summed milliseconds} of the calls bracketed since the last reset (synchronises the device)."""
+        out = {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        for name, e0, e1 in self._phase_events:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        if reset:
+            self._phase_events = []
+        return out
 
     # -- helpers ---------------------------------------------------------------------------------------
     @property
@@ -88,6 +120,7 @@ class Engine:
                                      f"(info={info[info != 0][:8].tolist()})")
 
     # -- a5 --------------------------------------------------------------------------------------------
+    @_phase("assembly (convolution matrices, E^-1, A = PQ)")
     def convmat(self, grid, ox, oy, dtype):
         """[B,nx,ny] real/complex grid -> [B,N,N] convolution matrix (torcwa/rcwa.py:1183-1204)."""
         B, nx, ny = grid.shape
@@ -121,6 +154,7 @@ class Engine:
                                      ctypes.addressof(be), out.data_ptr(), n, m * n, Bt, self.stream))
         return out
 
+    @_phase("assembly (convolution matrices, E^-1, A = PQ)")
     def inverse(self, A):
         """Returns inv(A) for [B,n,n] (A is not modified)."""
         self._check(A)
@@ -133,6 +167,7 @@ class Engine:
         self._info(info, "inverse")
         return A
 
+    @_phase("other (gemm / solve)")
     def solve(self, A, Bm):
         """Returns X with A X = B ([B,n,n], [B,n,r]); inputs are not modified."""
         self._check(A, Bm)
@@ -144,6 +179,7 @@ class Engine:
         return X
 
     # -- a7 --------------------------------------------------------------------------------------------
+    @_phase("eigendecomposition (trx_eig)")
     def eig(self, A, destroy=False, refine_steps=0):
         """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14).
 
@@ -168,6 +204,7 @@ class Engine:
         self._info(info, "eig")
         return w, V
 
+    @_phase("adjoint (eig backward, solves)")
     def eig_backward(self, w, V, gw, gV, broadening):
         """gA of the reference's broadened eig adjoint (torcwa/torch_eig.py:19-44) in one library call."""
         B, n, _ = V.shape
@@ -183,6 +220,7 @@ class Engine:
         return gA
 
     # -- a6 / a8 / a9 ----------------------------------------------------------------------------------
+    @_phase("assembly (convolution matrices, E^-1, A = PQ)")
     def build_pq(self, E, Einv, M, Minv, kx, ky):
         B, N, _ = E.shape
         dt = E.dtype
@@ -192,6 +230,7 @@ class Engine:
                                          self._c(kx).data_ptr(), self._c(ky).data_ptr(), N, B, P.data_ptr(), Q.data_ptr(), self.stream))
         return P, Q
 
+    @_phase("layer S-matrix (V = P^-1 W Kz, trx_layer_smatrix)")
     def hmodes(self, E, mu, kx, ky, W, kz):
         """V = P^-1 W diag(kz) for homogeneous mu [B] via the rank-N structure of P (include/trx.h: trx_hmodes)."""
         B, n, _ = W.shape
@@ -207,6 +246,7 @@ class Engine:
         self._info(info, "hmodes")
         return V
 
+    @_phase("layer S-matrix (V = P^-1 W Kz, trx_layer_smatrix)")
     def layer_smatrix(self, P, Q, W, kzfac, vfinv, phase, *, use_q=False, want_c=True, V=None):
         """Layer S-matrix (torcwa/rcwa.py:1244-1281).  vfinv: [4,B,N]; returns S11, S21, V, Cplus, Cminus.
         V given (from hmodes): the H-field modes are taken as input (use_q = 2 of the C ABI)."""
@@ -233,6 +273,7 @@ class Engine:
         self._info(info, "layer_smatrix")
         return S11, S21, V, cp, cm
 
+    @_phase("Redheffer star products")
     def redheffer(self, Sm, Sn):
         """Star product of two S-matrices given as lists [S11,S21,S12,S22] of [B,n,n] (torcwa/rcwa.py:1283-1306).
         Returns (Sout list, X1, X2, Y1, Y2) with the four C-propagation factors."""
@@ -254,6 +295,7 @@ class Engine:
         return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
 
 
+    @_phase("Redheffer star products")
     def redheffer_halfspace(self, side, bd, S, want_xy=True):
         """Star product with a block-diagonal half-space S-matrix (side 0: Sin * S, side 1: S * Sout).
         bd: [4,4,B,N] diagonals (see include/trx.h).  want_xy=False (no coupling lists to propagate) lets side 0 use the
@@ -279,6 +321,7 @@ class Engine:
         X, Y = XY[0], XY[1]
         return out, X[:, :, :n], X[:, :, n:], Y[:, :, :n], Y[:, :, n:]
 
+    @_phase("assembly (convolution matrices, E^-1, A = PQ)")
     def build_a(self, E, Einv, mu, kx, ky):
         """A = P Q for homogeneous mu [B] via the block structure (two N^3 GEMMs)."""
         B, N, _ = E.shape
