@@ -919,7 +919,7 @@ __device__ __forceinline__ void chain_window(int ilo, int ihi, int k, int tau, i
 // back; (2) the same buffer becomes U = I and the log is replayed onto it (bulge s's wave rotates its two columns, one barrier
 // per chain step).
 //
-// SUPER-STEPS (one chain per sweep, fp32): a launch takes the chain through `nsteps` consecutive windows.  Window step s + 1 needs, of
+// SUPER-STEPS (one chain per sweep): a launch takes the chain through `nsteps` consecutive windows.  Window step s + 1 needs, of
 // everything off window s, only the NEW COLUMNS it slides over to have received U_s^H from the left -- so the workgroup applies U_s^H itself
 // to the band [w1_s, E) right of its window (E = end of the band all steps of the launch share, <= nsteps * 31 + ... columns; one 16-column
 // strip per wave on the matrix cores, U_s converted in place to the split re/im planes the strip code reads), publishes (w0, w1, E) in
@@ -1056,10 +1056,10 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
         const int ww = w1 - w0;
         if (band_e == 0) {
-            // in-kernel band: fp32, one chain per sweep.  Every window of this launch ends at most (QW - 2 k - 1) columns further right
+            // in-kernel band: one chain per sweep.  Every window of this launch ends at most (QW - 2 k - 1) columns further right
             // than the one before, and the first window of the NEXT launch as well: all of them lie left of E.
             band_e = w1;
-            if constexpr (sizeof(T) == 4) { if (kc == 1 && band_on) { band_e = w1 + nsteps * (QW - 2 * k - 1); if (band_e > n) band_e = n; } }
+            if (kc == 1) { band_e = w1 + nsteps * (QW - 2 * k - 1); if (band_e > n) band_e = n; }
         }
         {
             // window load: QW*QW/WTHREADS independent (clamped) global loads per thread in flight, then the LDS fill
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             }
             __syncthreads();
         }
-        const bool do_band = sizeof(T) == 4 && band_e > w1;            // (workgroup-uniform; constant false in fp64)
+        const bool do_band = band_e > w1;            // (workgroup-uniform)
         {
             // U goes to the log; for the band update also, through registers, into split planes over the same LDS (zero outside ww x ww)
             const int c = t & (QW - 1), r4 = t / QW;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
                     if (r < ww) U[r * QW + c] = hv[i];
                 }
             }
-            if constexpr (sizeof(T) == 4) if (do_band) {
+            if (do_band) {
                 if (t == 0) *sflag = 0;
                 __syncthreads();                         // every thread holds its part of U; the buffer may be overwritten
                 int dense = 0;
@@ -1213,9 +1213,9 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             QrLink l; l.w0 = w0; l.w1 = w1; l.kind = QRL_CHASE; l.e = band_e;
             links[s * kc] = l;
         }
-        if constexpr (sizeof(T) == 4) if (do_band) {
+        if (do_band) {
             // left update of the band [w1, band_e): one 16-column strip per wave (16 waves)
-            const bool band = *sflag == 0;
+            const bool band = band_on && *sflag == 0;       // (knob slab_band: dense product although the unitary is banded)
             const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
             for (int a0 = w1 + 16 * wv; a0 < band_e; a0 += 16 * (WTHREADS / 64)) {
                 SlabStrip<T> d;
@@ -1518,8 +1518,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // shorter chain: 5.62 s (1 chain, AED 48) -> 5.16 s (3 chains) -> 4.79 s (3 chains, AED 64) for the whole forward solve
     // (profiles/r02_single_matrix_knobs.txt).
     const int band_on = K.band != 1;
-    // window steps per launch: the in-kernel band update exists in fp32 for one chain per sweep (the mixed-precision route's first stage)
-    const int super = (sizeof(T) == 4 && kc == 1) ? (K.super ? K.super : 4) : 1;
+    // window steps per launch: super-steps need one chain per sweep (several chains advance in lock-step, one window step per launch)
+    const int super = kc == 1 ? (K.super ? K.super : 4) : 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
