@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--cyclic", action="store_true", help="config 4, N > 1: rank r solves points r, r + N, ... instead of a contiguous block (SURVEY.md 8(e))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
+    ap.add_argument("--eig-route", default="auto", choices=["auto", "mixed", "fp64"], help="eigensolver route of the sweep drivers (torcwa_amd.sweep.solve_stack_sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
     ap.add_argument("--cpu-points", type=int, default=3, help="sweep points the CPU baseline times (>= 1)")
@@ -193,9 +194,9 @@ def run_step(freq, grids, order, engine, args, chunk):
         return run_step_topopt(grids, order, engine)
     if args.config == 3:
         return solve_stack_sweep(freq, grids, order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64, precision=args.precision, engine=engine,
-                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False)
+                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False, eig_route=args.eig_route)
     return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
-                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False)
+                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False, eig_route=args.eig_route)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -337,7 +338,7 @@ _EIG_STAGE = ("apply_links_kernel<0>", "apply_links_kernel<1>", "qr_prepare_kern
 
 
 def eig_is_mixed(args, n, chunk):
-    return args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5
+    return args.precision == "high" and os.environ.get("TRX_EIG_VEC", "0") in ("0", "3") and n >= 256 and chunk >= 8 and args.config != 5 and args.eig_route != "fp64"
 
 
 def read_prof_tags(engine):
@@ -688,8 +689,9 @@ def main():
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,
                        "chunk": int(chunk), "streams": args.streams,
-                       "eig_route": ("mixed: fp32 eigendecomposition + fp64 Newton refinement; matrices the refinement cannot certify are redone in fp64 "
-                                     "inside trx_eig (last call of the run: %d of %d)" % (int(getattr(engine, "last_eig_fallback", 0)), int(chunk))
+                       "eig_route": ("--eig-route %s: mixed = fp32 eigendecomposition + fp64 Newton refinement, matrices the refinement cannot certify redone in fp64 "
+                                     "inside trx_eig; auto = mixed until a call of the sweep had to redo matrices, then fp64 for the rest of THAT sweep call "
+                                     "(last eig call of the run redid %d of its matrices)" % (args.eig_route, int(getattr(engine, "last_eig_fallback", 0)))
                                      if eig_is_mixed(args, n, chunk) else "fp64 (Hessenberg, multi-shift QR, Schur vectors)")
                                     if args.precision == "high" else "fp32 (Hessenberg, multi-shift QR, Schur vectors)",
                        "sharding": ("cyclic (rank r: points r, r + N, ...)" if cyclic else "contiguous blocks") if world > 1 else None,

@@ -140,6 +140,41 @@ def test_homogeneity_rule_matches_the_reference():
     assert obj._is_homogeneous(torch.tensor([2.0, 3.0, 4.0])) and not obj._is_homogeneous(torch.tensor([2.0, 3.0]))
 
 
+def test_eig_route_policy_is_scoped_to_the_solver_or_sweep_call():
+    """BatchedRCWA._eig_call: "auto" asks the library's automatic (mixed-precision) route until a call reports matrices redone in fp64, then the
+    all-fp64 route -- for eigenproblems of that size handled by THIS solver object / sweep call only (the hint is a dict created per call)."""
+    from torcwa_amd.batched import BatchedRCWA
+
+    class FakeEngine:
+        def __init__(self):
+            self.calls, self.last_eig_fallback, self.next_fallback = [], 0, 0
+
+        def eig(self, A, destroy=False, refine_steps=0, route=0):
+            self.calls.append(route)
+            self.last_eig_fallback = self.next_fallback if route != 1 else 0
+            return None, None
+
+    def solver(eng, route, hint):
+        o = BatchedRCWA.__new__(BatchedRCWA)
+        o.engine, o.eig_route, o._route_hint = eng, route, hint
+        return o
+
+    eng = FakeEngine()
+    A = torch.zeros(2, 6, 6)
+    hint = {}
+    a, b = solver(eng, "auto", hint), solver(eng, "auto", hint)        # two chunks of one sweep call share the hint
+    a._eig_call(A, 2)
+    eng.next_fallback = 1
+    a._eig_call(A, 2)                   # this one had to redo a matrix
+    b._eig_call(A, 2)                   # -> the other chunk goes to fp64 directly
+    a._eig_call(torch.zeros(2, 8, 8), 2)        # another size: no hint
+    c = solver(eng, "auto", {})         # a new sweep call / solver starts fresh
+    c._eig_call(A, 2)
+    solver(eng, "fp64", {})._eig_call(A, 2)
+    solver(eng, "mixed", {})._eig_call(A, 2)
+    assert eng.calls == [0, 0, 1, 0, 0, 1, 3]
+
+
 def test_blockdiag2_algebra():
     from torcwa_amd.batched import BlockDiag2
     g = torch.Generator().manual_seed(0)

@@ -71,11 +71,14 @@ def _halfspace_V(kx, ky, epsmu):
 class BatchedRCWA:
     def __init__(self, freq, order, L, *, batch=None, dtype=torch.complex64, device=None, stable_eig_grad=True,
                  avoid_Pinv_instability=False, max_Pinv_instability=0.005, precision="high", engine=None,
-                 keep_coupling=True, fold_layers=False):
+                 keep_coupling=True, fold_layers=False, eig_route="auto", route_hint=None):
         if dtype != torch.complex64 and dtype != torch.complex128:                      # rcwa.py:37-41
             warnings.warn("Invalid simulation data type. Set as torch.complex64.", UserWarning)
             dtype = torch.complex64
         self._dtype = dtype
+        # eigensolver route of THIS solver: "auto" | "mixed" | "fp64" (see _eig_call); route_hint: a dict shared by the chunks of one sweep call
+        self.eig_route = eig_route
+        self._route_hint = route_hint if route_hint is not None else {}
         self.engine = engine if engine is not None else (default_engine() if device is None else Engine(device=device))
         self._device = self.engine.device
         # precision="high": c64 problems are computed in complex128 internally (the reference's own c64 path is only
@@ -246,7 +249,7 @@ class BatchedRCWA:
                 A = eng.build_a(E, Einv, mu_s, kxd, kyd) if mu_h else eng.gemm(P, Q)
                 del Einv
                 # mixed-precision eigensolver: two Newton steps for a complex64 problem (1e-5 gate), three for complex128 (engine.eig)
-                lam, W = eng.eig(A, destroy=True, refine_steps=3 if self._dtype == torch.complex128 else 2)      # torch_eig.py:14
+                lam, W = self._eig_call(A, refine_steps=3 if self._dtype == torch.complex128 else 2)      # torch_eig.py:14
                 del A
             kz = torch.sqrt(lam)
             kz = torch.where(torch.imag(kz) < 0, -kz, kz)                               # rcwa.py:1241
@@ -375,6 +378,22 @@ class BatchedRCWA:
             C[0].append(mm(Cn[0][k], X1))
             C[1].append(Cn[1][k] + mm(Cn[0][k], X2))
         return S, C
+
+    def _eig_call(self, A, refine_steps):
+        """trx_eig with this solver's route policy.  "fp64" / "mixed": as named.  "auto": the library's mixed-precision route, and -- scoped to THIS
+        solver object (or to the one sweep call whose chunks share `route_hint`), never beyond -- once a call had to redo matrices in fp64
+        (clusters of close eigenvalues beyond the refinement's exact treatment: symmetric meta-atoms, the dense spectra of large orders), the
+        following eigenproblems of the same size go to the all-fp64 route directly instead of paying for another failed attempt.  The hint is
+        created with the solver / sweep call and dies with it: results never depend on what the process solved before."""
+        eng = self.engine
+        key = int(A.shape[-1])
+        route = {"auto": 0, "mixed": 3, "fp64": 1}[self.eig_route]
+        if self.eig_route == "auto" and self._route_hint.get(key):
+            route = 1
+        lam, W = eng.eig(A, destroy=True, refine_steps=refine_steps, route=route)
+        if self.eig_route == "auto" and route == 0 and eng.last_eig_fallback > 0:
+            self._route_hint[key] = True
+        return lam, W
 
     def _is_homogeneous(self, v):
         if isinstance(v, (float, complex)):

@@ -1627,17 +1627,20 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               }
               const int units = cdiv_i(nstrip + 1, 4 * spw);
               TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
-              // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed)
+              // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
+              // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
+              // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
               if (kc > 1)
-                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 1, band_on); }
+                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
             q += ns;
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
         // deflation), so it cannot run beside it.
-        { ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-          const int parts = kc > 1 ? 2 : 3;
-          TRX_LAUNCH((apply_links_kernel<T, 1>), dim3((kc > 1 ? 1 : 2) * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, parts, band_on); }
+        if (kc == 1) {
+            ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
+            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on);
+        }
         return true;
     };
     if (!rc && qr_debug && hipMemsetAsync(dbg_dev, 0, sizeof(long long) * 24, s) != hipSuccess) rc = TRX_ERR_LAUNCH;

@@ -308,6 +308,14 @@ __global__ __launch_bounds__(64) void refine_solve_clusters_kernel(const cx<T>* 
     }
     // 4. cluster numbering and member lists (serial: a few hundred entries)
     if (t == 0) {
+        // diagnostic (TRX_EIG_DEBUG): number of coupled indices and the size of the largest component, whatever the limits below say
+        int big = 0;
+        for (int p = 0; p < nl; ++p) {
+            int cnt = 0;
+            if (lab[p] == p) for (int q = p; q < nl; ++q) cnt += lab[q] == p;
+            big = cnt > big ? cnt : big;
+        }
+        Tb.pad = (big << 16) | (nl & 0xFFFF);
         int ncl = 0;
         for (int p = 0; p < nl && !bad_s; ++p) {
             if (lab[p] == p) {
@@ -478,6 +486,18 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         int f1 = 0, f2 = 0, fl = 0, f32 = 0, f64 = 0, f128 = 0, f256 = 0;
         for (int b = 0; b < batch; ++b) { f1 += (hf[b] & 1) != 0; f2 += (hf[b] & 2) != 0; fl += hl[b] != 0; f32 += (hf[b] & 32) != 0; f64 += (hf[b] & 64) != 0; f128 += (hf[b] & 128) != 0; f256 += (hf[b] & 256) != 0; }
         fprintf(stderr, "libtrx eig_refine: cluster failures: > %d coupled indices %d, cluster > %d: %d, cluster count / singleton %d, small solver %d\n", RCL, f32, RCM, f64, f128, f256);
+        {
+            // largest component / coupled indices per matrix (of the LAST step's tables)
+            std::string line;
+            int worst = 0;
+            for (int b = 0; b < batch; ++b) {
+                int pad = 0;
+                (void)hipMemcpy(&pad, (const char*)R.pairX + (size_t)b * REFINE_CLUSTER_BYTES + sizeof(int), sizeof(int), hipMemcpyDeviceToHost);
+                if ((hf[b] & 64) || hf[b] == 0) worst = (pad >> 16) > worst ? (pad >> 16) : worst;        // (the table is only written when step 4 was reached)
+                if ((hf[b] & 64) || (hf[b] == 0 && b < 4)) line += " " + std::to_string(b) + ":" + std::to_string(pad >> 16) + "/" + std::to_string(pad & 0xFFFF);
+            }
+            fprintf(stderr, "libtrx eig_refine: largest component %d; matrix:largest/coupled%s\n", worst, line.c_str());
+        }
         fprintf(stderr, "libtrx eig_refine: n %d batch %d steps %d: any %d | matrices flagged: far-off %d, multi-coupled %d, LU %d | last step: max|E| %.3e max|lambda| %.3e (matrix 0), %.3e %.3e (matrix %d)\n",
                 n, batch, steps, hf[batch], f1, f2, fl, (double)he[0], (double)hm[0], (double)he[batch - 1], (double)hm[batch - 1], batch - 1);
     }

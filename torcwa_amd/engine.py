@@ -180,15 +180,18 @@ class Engine:
 
     # -- a7 --------------------------------------------------------------------------------------------
     @_phase("eigendecomposition (trx_eig)")
-    def eig(self, A, destroy=False, refine_steps=0):
+    def eig(self, A, destroy=False, refine_steps=0, route=0):
         """(w [B,n], V [B,n,n]) with A V = V diag(w) (torcwa/torch_eig.py:14).
 
         refine_steps: Newton steps of libtrx's mixed-precision route (complex128 input of at least 256 rows: fp32 eigendecomposition
         refined in fp64, include/trx.h "eig_refine"); 0 = the library default (2: the accuracy class of the all-fp64 pipeline; measured on
         MI355X, one step is NOT enough for the 1e-5 gate of a complex64 problem at order [15,15] -- the fp32 start of this pipeline leaves
-        max |E| ~ 2e-2 ... 2e-1 there)."""
+        max |E| ~ 2e-2 ... 2e-1 there).
+        route: 0 = the library's automatic choice (mixed precision for complex128 input with n >= 256 and batch >= 8), 1 = all-fp64 (all-fp32 for
+        complex64 input), 3 = mixed wherever n >= 8 (include/trx.h "eig_vec").  After the call `last_eig_fallback` holds the number of matrices the
+        mixed route redid in fp64."""
         self._check(A)
-        opts = int(refine_steps) & 0xF          # per-call option word of trx_eig_opts (no process-global knob is touched: thread-safe)
+        opts = (int(refine_steps) & 0xF) | ((int(route) & 0xF) << 4)          # per-call option word of trx_eig_opts (no process-global knob is touched: thread-safe)
         # (No route policy lives here any more: matrices the mixed-precision route cannot certify -- clusters of close eigenvalues beyond the
         # refinement's exact treatment -- are redone in fp64 INSIDE the library, as a sub-batch; results do not depend on call history.)
         A = self._c(A) if destroy else A.clone()

@@ -77,9 +77,10 @@ def rectangle_density(nx, ny, Lx, Ly, Wx, Wy, Cx, Cy, theta=0.0, edge_sharpness=
 
 
 def _solve_chunk(freq, layers, order, L, eps_in, eps_out, inc_ang, azi_ang, dtype, precision, engine, orders,
-                 polarization, direction, port, check_info):
+                 polarization, direction, port, check_info, eig_route="auto", route_hint=None):
     """layers: list of (thickness, eps[, mu]); thickness scalar or [b]; eps/mu scalar, [b] or [b,nx,ny]."""
-    sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False, fold_layers=True)
+    sim = BatchedRCWA(freq, order, L, dtype=dtype, precision=precision, engine=engine, keep_coupling=False, fold_layers=True,
+                      eig_route=eig_route, route_hint=route_hint)
     if eps_in is not None:
         sim.add_input_layer(eps=eps_in)
     if eps_out is not None:
@@ -129,10 +130,13 @@ def _slice(v, lo, hi, B):
 
 def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0, dtype=torch.complex64,
                       precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),), polarization="xx",
-                      direction="forward", port="transmission", check_info=True):
+                      direction="forward", port="transmission", check_info=True, eig_route="auto"):
     """B sweep points of a multi-layer stack (BASELINE.json configs 2-4): the reference's per-point Python loop
     (example/Example1-1.ipynb, Example3.ipynb) as chunks of a batched solve.  `layers` as in `_solve_chunk`, with
-    per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)]."""
+    per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)].
+
+    eig_route: "auto" (mixed-precision eigensolver; once a chunk of THIS call had to redo matrices in fp64, the remaining layers and chunks
+    of this call use the all-fp64 route -- BatchedRCWA._eig_call), "mixed" or "fp64"."""
     from .engine import default_engine
     B = freq.shape[0]
     eng = engine if engine is not None else default_engine()
@@ -143,12 +147,14 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
         chunk = -(-B // streams)
     spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
     outs = [None] * len(spans)
+    route_hint = {}                     # shared by the chunks of this call only
 
     def run(i):
         lo, hi = spans[i]
         lays = [tuple(_slice(v, lo, hi, B) for v in lay) for lay in layers]
         outs[i] = _solve_chunk(freq[lo:hi], lays, order, L, _slice(eps_in, lo, hi, B), _slice(eps_out, lo, hi, B), _slice(inc_ang, lo, hi, B),
-                               _slice(azi_ang, lo, hi, B), dtype, precision, engine, orders, polarization, direction, port, check_info)
+                               _slice(azi_ang, lo, hi, B), dtype, precision, engine, orders, polarization, direction, port, check_info,
+                               eig_route=eig_route, route_hint=route_hint)
 
     dev = freq.device
     try:
