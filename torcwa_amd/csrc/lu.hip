@@ -221,20 +221,42 @@ __global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ A
     const cx<T> ri = (pv.x != T(0) || pv.y != T(0)) ? crecip(pv) : cx<T>(T(0), T(0));
     int r0, r1;
     lu_split_rows<T>(n, k0, W, w, r0, r1);
-    // 16 lanes per row (2 columns each), 16 rows in flight
+    // 16 lanes per row (2 columns each), 16 rows per pass, LUR passes in flight: the loads of LUR x 16 rows are issued before the first
+    // result is needed (one pass at a time the loop was a chain of ~15 dependent L2 round trips per column launch: 52 us per launch at
+    // batch 128 for 1.2 TB/s of traffic -- latency, not bandwidth)
     const int cpart = t & 15, rpart = t >> 4;
     T best = T(-1);
     int bi = n;
-    for (int r = r0 + rpart; r < r1; r += LST / 16) {
-        bool done = false;
-        for (int q = 0; q <= j; ++q) done |= (chosen[q] == r);
-        if (done) continue;
-        cx<T>* row = A + (long)r * lda + k0;
-        const cx<T> l = row[j] * ri;             // the multiplier itself stays unscaled in memory until lu_split_scale_kernel
-        for (int c = j + 1 + cpart; c < jb; c += 16) {
-            const cx<T> v = row[c] - l * prow[c];
-            row[c] = v;
-            if (c == j + 1) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
+    constexpr int LUR = 4;
+    static_assert(NB <= 32, "two columns per lane cover a panel");
+    const int c1 = j + 1 + cpart, c2 = c1 + 16;
+    const cx<T> u1 = c1 < jb ? prow[c1] : cx<T>(T(0), T(0)), u2 = c2 < jb ? prow[c2] : cx<T>(T(0), T(0));
+    for (int rb = r0 + rpart; rb < r1; rb += LUR * (LST / 16)) {
+        cx<T> lv[LUR], a1[LUR], a2[LUR];
+        bool on[LUR];
+#pragma unroll
+        for (int u = 0; u < LUR; ++u) {
+            const int r = rb + u * (LST / 16);
+            bool done = r >= r1;
+            for (int q = 0; q <= j; ++q) done |= (chosen[q] == r);
+            on[u] = !done;
+            const cx<T>* row = A + (long)(done ? r0 : r) * lda + k0;          // (a valid address for the rows that sit out)
+            lv[u] = row[j];
+            a1[u] = row[c1 < jb ? c1 : j];
+            a2[u] = row[c2 < jb ? c2 : j];
+        }
+#pragma unroll
+        for (int u = 0; u < LUR; ++u) {
+            if (!on[u]) continue;
+            const int r = rb + u * (LST / 16);
+            cx<T>* row = A + (long)r * lda + k0;
+            const cx<T> l = lv[u] * ri;             // the multiplier itself stays unscaled in memory until lu_split_scale_kernel
+            if (c1 < jb) {
+                const cx<T> v = a1[u] - l * u1;
+                row[c1] = v;
+                if (cpart == 0) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
+            }
+            if (c2 < jb) row[c2] = a2[u] - l * u2;
         }
     }
     if (j + 1 < jb) {
