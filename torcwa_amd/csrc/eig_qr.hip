@@ -1390,7 +1390,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1412,6 +1412,7 @@ static QrKnobs& qr_knobs() {
         q.band = geti("TRX_SLAB_BAND", 0, 2, 0);              // 0 / 2: skip the structurally zero blocks of a chain unitary, 1: dense product always
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
+        q.defer = geti("TRX_QR_DEFER", 0, 2, 0);              // right / Z update: 0 automatic, 1 behind every (super-)step, 2 once per sweep
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1469,6 +1470,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "qr_chains") { slot = &k.chains; hi = QKC; }
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
+    else if (s == "qr_defer") { slot = &k.defer; hi = 2; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1519,7 +1521,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // (profiles/r02_single_matrix_knobs.txt).
     const int band_on = K.band != 1;
     // window steps per launch: super-steps need one chain per sweep (several chains advance in lock-step, one window step per launch)
-    const int super = kc == 1 ? (K.super ? K.super : 4) : 1;
+    const int super = kc == 1 ? (K.super ? K.super : (sizeof(T) == 4 ? 4 : 8)) : 1;          // measured: fp32 4 (2 / 8 within 0.5 %), fp64 8 (28.4 vs 28.1 layer-solves/s on the all-fp64 route)
+    const bool defer = kc == 1 && K.defer != 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1630,14 +1633,14 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
               // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
               // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
-              if (kc > 1)
+              if (!defer)
                   TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
             q += ns;
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
         // deflation), so it cannot run beside it.
-        if (kc == 1) {
+        if (defer) {
             ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
             TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on);
         }
