@@ -72,10 +72,12 @@ __device__ __forceinline__ void rot_cols(const Rot<T>& R, cx<T>& x, cx<T>& y) {
 
 // 1 / sqrt(x) for the rotation generator.  rsqrt(float) resolves to the DOUBLE overload in HIP: the fp32 kernels of round 3 carried, per
 // call, v_cvt_f64_f32 + v_rsq_f64 + a five-instruction fp64 refinement + v_cvt_f32_f64 -- twice per rotation, on the critical path of every
-// chain step.  A plain v_rsq_f32 (1 ulp, or refined in fp32) is cheaper but leaves the rotations unitary to only ~5 ulp, and the
-// eigen-refinement behind the fp32 solver feels that (exactly degenerate spectra: 1e-8 instead of 1e-14 after two Newton steps, emulator).
-// So fp32 takes ONE unrefined v_rsq_f64 of the fp64 argument: good to ~2^-26, i.e. correctly rounded for a float, no under / overflow of
-// the product |f|^2 d^2, five dependent instructions.
+// chain step.  A plain v_rsq_f32 is cheaper still but leaves the rotations unitary to only a few fp32 ulp.  fp32 takes ONE unrefined v_rsq_f64
+// of the fp64 argument: no under / overflow of the product |f|^2 d^2, five dependent instructions.  Its accuracy is NOT claimed beyond what
+// the ISA documents for v_rsq_f64 (about single precision, ~1e-7 relative -- the CPU emulator computes an exact 1/sqrt and cannot vouch for the
+// hardware): the rotations are therefore unitary to fp32 rounding, no better, and that is all the fp32 stage needs -- its results go through
+// Newton refinement in fp64 (mixed route) or are a precision="native" answer held to the fp32 gates of the GPU suite (residual 5e-6,
+// tests/test_eig.py::test_eig_random[complex64], test_eig_super_steps_fp32).
 __device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt(x); }
 __device__ __forceinline__ float fast_rsqrt_f64arg(double x) { return (float)__builtin_amdgcn_rsq(x); }
 

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(LST) void lu_split_scale_kernel(cx<T>* __restrict__
 // ballot; the moves themselves are not replayed swap by swap: no row has moved physically yet, so the final map says where every affected row
 // goes -- all sources are staged in LDS (2 jb rows x jb columns, coalesced), then written to their destinations.  Same interchange sequence,
 // same result, bit for bit.
+static_assert(2 * NB <= 64, "lu_split_final_kernel keeps one map entry per lane of ONE 64-wide wavefront (gfx950: wave64 only)");
 template <class T>
 __global__ __launch_bounds__(64) void lu_split_final_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int* __restrict__ piv_all) {
     __shared__ int key[2 * NB], pos[2 * NB];             // original row -> current position, for the rows that have moved (entry l on lane l)
