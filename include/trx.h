@@ -15,7 +15,7 @@
  *    per outer iteration (about n / 16 of them per sub-batch) the host reads a 12-byte progress summary from pinned memory, one
  *    iteration after it was produced, and for batch >= 8 it runs the QR phase of 2-4 sub-batches on internal non-blocking streams
  *    (forked from and joined back into `stream` with events) so that their latency-bound steps overlap; on the mixed-precision route it
- *    also reads one flag word after the refinement.  Those streams and events come from
+ *    also reads the per-matrix flag words after the refinement.  Those streams and events come from
  *    a process-wide pool created on first use (nothing is created or destroyed per call), and no environment variable is read per call.
  *  - Return value: 0 = ok, <0 = TRX_ERR_* (bad argument / launch failure).  Numerical failures (singular pivot,
  *    eigensolver non-convergence) are reported LAPACK-style in the device-resident `info[batch]` array.
@@ -99,9 +99,11 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       followed by a sweep in the same outer iteration; 0 switches that sweep off.  No automatic value.
  *   "qr_moves"    0-64  LITERAL bound, default 12 (TRX_QR_MOVES): undeflatable eigenvalues an AED moves out of the way; 0 = no reordering.
  *   "qr_rotb"     1 = the in-LDS Schur solver of the AED broadcasts each rotation with ds_bpermute (round-3 code); default: v_readlane (TRX_QR_ROTB)
- *   "qr_super"    1-8   window steps per launch of the chase kernel (fp32, one chain per sweep: TRX_QR_SUPER)     auto: 4.  The workgroup applies each
+ *   "qr_super"    1-8   window steps per launch of the chase kernel (one chain per sweep: TRX_QR_SUPER)     auto: 4 (fp32), 8 (fp64).  The workgroup applies each
  *                       window's unitary itself to the band of columns the next windows slide over; the left update beyond the band is one
  *                       launch per super-step, the right update of H and the update of Z one launch per sweep (link log of the sweep)
+ *   "qr_defer"    1 = right update of H and update of Z after every super-step instead of once per sweep (TRX_QR_DEFER)   auto: once per sweep
+ *                       when the sweep has one chain; with 2-3 chains the following chain reads the rows, so it is per step
  *   "slab_spw"    1, 2, 4  strips per wave of the left update (TRX_SLAB_SPW)           auto: 1
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chase unitary
  *   Eigenvector route of trx_eig

@@ -1,5 +1,5 @@
 // Micro-test of the gfx950 direct global -> LDS load (global_load_lds_dwordx4) issued from inline assembly, as used by the column
-// ring of torcwa_amd/csrc/eig_invit.hip: where do the 16 bytes of lane L land (M0 base + L * 16 expected), does s_waitcnt vmcnt(N)
+// ring of the inverse-iteration kernel (eig_invit.hip, removed in round 5): where do the 16 bytes of lane L land (M0 base + L * 16 expected), does s_waitcnt vmcnt(N)
 // with N loads still in flight order it against a later ds_read, and what does a deep ring of them cost per step.
 //   hipcc --offload-arch=gfx950 -O3 tests/micro/lds_dma.hip -o tests/micro/_build/lds_dma && tests/micro/_build/lds_dma
 #include <hip/hip_runtime.h>
