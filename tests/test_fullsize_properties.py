@@ -81,8 +81,9 @@ def test_native_c64_precision_is_reference_class():
     hi = solve_single_layer_sweep(freq, grids, 300., [15, 15], [300., 300.], precision="high", **kw).cpu().numpy()
     ref = solve_single_layer_sweep(freq, grids.to(torch.complex128), 300., [15, 15], [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex128).cpu().numpy()
     nat = solve_single_layer_sweep(freq, grids, 300., [15, 15], [300., 300.], precision="native", **kw).cpu().numpy()
+    # measured on MI355X (profiles/r05_verify.txt): native 7.0e-4, high 3.1e-8; the reference's own complex64 run: 2e-3
     assert np.abs(hi - ref).max() / np.abs(ref).max() < 1e-5
-    assert np.abs(nat - ref).max() / np.abs(ref).max() < 2e-2
+    assert np.abs(nat - ref).max() / np.abs(ref).max() < 2e-3
     print("native-c64 rel err:", np.abs(nat - ref).max() / np.abs(ref).max(), " high:", np.abs(hi - ref).max() / np.abs(ref).max())
 
 
