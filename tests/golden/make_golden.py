@@ -216,7 +216,7 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--fields-larger", "--grad", "--fullsize", "--geometry", "--rayleigh")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--fields-larger", "--grad", "--fullsize", "--geometry", "--rayleigh", "--shape-grad")):
     main()
 
 
@@ -563,3 +563,57 @@ def main_rayleigh():
 
 if __name__ == "__main__" and "--rayleigh" in sys.argv:
     main_rayleigh()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# shape derivatives: the FoM differentiated through the level-set geometry (example/Example4.ipynb: d|txx|^2 / dR of a cylinder,
+# exact and stabilised eigen-gradient; example/Example5.ipynb: d|tyy - txx| / d(Wx, Wy) of a rectangle), at a small order
+# ---------------------------------------------------------------------------------------------------------
+def main_shape_grad():
+    out = {}
+    geo = torcwa.geometry(Lx=300., Ly=300., nx=120, ny=120, edge_sharpness=60., dtype=torch.float64, device=torch.device("cpu"))
+    geo.grid()
+    # cylinder (C4v-symmetric: degenerate mode pairs -- the case the broadened adjoint exists for)
+    for tag, stable, bp in (("exact", False, 1e-10), ("bpe-10", True, 1e-10), ("bpnone", True, None)):
+        torcwa.Eig.broadening_parameter = bp
+        for R0 in (88., 97.):
+            R = torch.tensor(R0, dtype=torch.float64, requires_grad=True)
+            sim = torcwa.rcwa(freq=1 / 473., order=[3, 3], L=[300., 300.], dtype=torch.complex128, device=torch.device("cpu"), stable_eig_grad=stable)
+            sim.add_input_layer(eps=1.46 ** 2)
+            sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+            m = geo.circle(R=R, Cx=150., Cy=150.)
+            sim.add_layer(thickness=600., eps=m * 2.0709 ** 2 + (1. - m))
+            sim.solve_global_smatrix()
+            txx = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+            T = torch.abs(txx) ** 2
+            T.backward()
+            out[f"circle_{tag}_R{int(R0)}_txx"] = txx.detach().numpy()
+            out[f"circle_{tag}_R{int(R0)}_grad"] = R.grad.numpy()
+            print("circle", tag, R0, "Txx", float(T), "dTxx/dR", float(R.grad))
+    torcwa.Eig.broadening_parameter = 1e-10
+    # rectangle, rotated so that no mirror symmetry is left (simple spectrum)
+    lam_tab = np.load(os.path.join(HERE, "asih_table.npz"))
+    eps_si = complex(lam_tab["nk"][-2]) ** 2
+    out["eps_si"] = np.complex128(eps_si)
+    for th in (0.0, 0.3):
+        W = torch.tensor([180., 100.], dtype=torch.float64, requires_grad=True)
+        theta = torch.tensor(th, dtype=torch.float64, requires_grad=True)
+        sim = torcwa.rcwa(freq=1 / 532., order=[3, 3], L=[300., 300.], dtype=torch.complex128, device=torch.device("cpu"))
+        sim.add_input_layer(eps=1.46 ** 2)
+        sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+        m = geo.rectangle(Wx=W[0], Wy=W[1], Cx=150., Cy=150., theta=theta)
+        sim.add_layer(thickness=250., eps=m * eps_si + (1. - m))
+        sim.solve_global_smatrix()
+        txx = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+        tyy = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="yy", ref_order=[0, 0])
+        delta = torch.abs(tyy - txx)
+        delta.sum().backward()
+        key = f"rect_th{int(round(th * 10))}"
+        out[key + "_txx"], out[key + "_tyy"] = txx.detach().numpy(), tyy.detach().numpy()
+        out[key + "_gradW"], out[key + "_gradtheta"] = W.grad.numpy(), theta.grad.numpy()
+        print("rectangle theta", th, "delta", float(delta), "d/dW", W.grad.numpy(), "d/dtheta", float(theta.grad))
+    np.savez_compressed(os.path.join(HERE, "shape_grad.npz"), **out)
+
+
+if __name__ == "__main__" and "--shape-grad" in sys.argv:
+    main_shape_grad()

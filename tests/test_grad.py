@@ -72,3 +72,69 @@ def test_gradient_through_forced_q_branch(backend):
     assert np.isfinite(g1).all()
     assert abs(f1 - f0) / abs(f0) < 1e-9
     assert np.abs(g1 - g0).max() / np.abs(g0).max() < 1e-6
+
+
+def _geo(eng):
+    import torcwa_amd
+    return torcwa_amd.geometry(Lx=300., Ly=300., nx=120, ny=120, edge_sharpness=60., dtype=torch.float64, device=eng.device)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("tag,stable,bp", [("exact", False, 1e-10), ("bpe-10", True, 1e-10), ("bpnone", True, None)])
+def test_shape_derivative_of_a_cylinder(backend, tag, stable, bp):
+    """example/Example4.ipynb at a small order: |txx|^2 differentiated through the level-set geometry with respect to the radius of a
+    cylinder (C4v: degenerate mode pairs), exact and stabilised eigen-gradient, against the reference's autograd
+    (tests/golden/shape_grad.npz; make_golden.py --shape-grad).  1e-6 relative, as the other gradient cases."""
+    import torcwa_amd
+    eng = make_engine(backend)
+    g = np.load(os.path.join(GOLDEN, "shape_grad.npz"))
+    old = torcwa_amd.Eig.broadening_parameter
+    torcwa_amd.Eig.broadening_parameter = bp
+    try:
+        for R0 in ((97,) if backend == "emu" and tag != "bpe-10" else (88, 97)):          # emulator time budget
+            R = torch.tensor(float(R0), dtype=torch.float64, device=eng.device, requires_grad=True)
+            sim = torcwa_amd.rcwa(freq=1 / 473., order=[3, 3], L=[300., 300.], dtype=torch.complex128, engine=eng, stable_eig_grad=stable)
+            sim.add_input_layer(eps=1.46 ** 2)
+            sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+            m = _geo(eng).circle(R=R, Cx=150., Cy=150.)
+            sim.add_layer(thickness=600., eps=m * 2.0709 ** 2 + (1. - m))
+            sim.solve_global_smatrix()
+            txx = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+            (torch.abs(txx) ** 2).sum().backward()
+            ref_t = complex(np.asarray(g[f"circle_{tag}_R{R0}_txx"]).reshape(-1)[0])
+            ref_g = float(np.asarray(g[f"circle_{tag}_R{R0}_grad"]).reshape(-1)[0])
+            assert abs(complex(txx.detach().reshape(-1)[0]) - ref_t) / abs(ref_t) < 1e-9
+            # scale of the derivative: d|txx|^2/dR reaches 1.14 / nm at R = 97 and passes through zero near R = 88
+            assert abs(float(R.grad) - ref_g) < 1e-6 * max(abs(ref_g), 1e-2), (float(R.grad), ref_g)
+    finally:
+        torcwa_amd.Eig.broadening_parameter = old
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("th", [0.0, 0.3])
+def test_shape_derivative_of_a_rectangle(backend, th):
+    """example/Example5.ipynb's objective |tyy - txx| differentiated with respect to (Wx, Wy) and the rotation angle of the rectangle
+    (theta = 0: mirror-symmetric, d/dtheta vanishes; theta = 0.3: no symmetry left), against the reference's autograd."""
+    import torcwa_amd
+    eng = make_engine(backend)
+    g = np.load(os.path.join(GOLDEN, "shape_grad.npz"))
+    eps_si = complex(g["eps_si"])
+    W = torch.tensor([180., 100.], dtype=torch.float64, device=eng.device, requires_grad=True)
+    theta = torch.tensor(th, dtype=torch.float64, device=eng.device, requires_grad=True)
+    sim = torcwa_amd.rcwa(freq=1 / 532., order=[3, 3], L=[300., 300.], dtype=torch.complex128, engine=eng)
+    sim.add_input_layer(eps=1.46 ** 2)
+    sim.set_incident_angle(inc_ang=0., azi_ang=0.)
+    m = _geo(eng).rectangle(Wx=W[0], Wy=W[1], Cx=150., Cy=150., theta=theta)
+    sim.add_layer(thickness=250., eps=m * eps_si + (1. - m))
+    sim.solve_global_smatrix()
+    txx = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="xx", ref_order=[0, 0])
+    tyy = sim.S_parameters(orders=[0, 0], direction="forward", port="transmission", polarization="yy", ref_order=[0, 0])
+    torch.abs(tyy - txx).sum().backward()
+    key = f"rect_th{int(round(th * 10))}"
+    for v, name in ((txx, "_txx"), (tyy, "_tyy")):
+        ref = complex(np.asarray(g[key + name]).reshape(-1)[0])
+        assert abs(complex(v.detach().reshape(-1)[0]) - ref) / abs(ref) < 1e-9
+    refW = np.asarray(g[key + "_gradW"])
+    assert np.abs(W.grad.cpu().numpy() - refW).max() / np.abs(refW).max() < 1e-6
+    ref_th = float(np.asarray(g[key + "_gradtheta"]).reshape(-1)[0])
+    assert abs(float(theta.grad) - ref_th) < 1e-6 * max(abs(ref_th), np.abs(refW).max())

@@ -199,7 +199,7 @@ def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
 
     chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default None = as many as the free HBM holds with
               10 % headroom, `auto_chunk`).  At order [15,15] (n = 1922) a point costs about 0.6 GB allocated / 0.9 GB reserved, so about 256 points
-              fit the 288 GB of an MI355X, and larger chunks are faster (measured: 23.6 / 28.8 / 31.6 layer-solves/s at 64 / 128 / 256 points).
+              fit the 288 GB of an MI355X, and larger chunks are faster (measured, round 5: 15.7 / 22.1 / 27.9 / 32.2 layer-solves/s at 16 / 32 / 64 / 128 points).
     streams : number of HIP streams / host threads the chunks are dealt to (default 1: on MI355X one stream was measured
               faster -- the QR window kernel needs 133 KB of LDS and evicts the slab workgroups of the other stream).
     """
