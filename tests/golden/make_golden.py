@@ -216,7 +216,7 @@ def main():
                         rect_row150=rect[150], rect30_sum=rect30.sum(), rect30_row150=rect30[150])
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--fields-larger", "--grad", "--fullsize", "--geometry", "--rayleigh", "--shape-grad")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--fields", "--fields-larger", "--grad", "--fullsize", "--fullorder", "--geometry", "--rayleigh", "--shape-grad")):
     main()
 
 
@@ -427,16 +427,16 @@ def config5_density(nx=700, ny=300, beta=6.0):
     return rho.astype(np.float32)
 
 
-def main_config5():
-    """config 5: Example-6 geometry L=[700,300], 700x300 grid, order [15,8] (the notebook's own order), complex128,
-    FoM = sum over the four polarisation pairs of |t_(1,0)|^2, gradient w.r.t. the density through the stabilised Eig."""
+def main_config5(order=(15, 8), name="config5_o15_8_c128"):
+    """config 5: Example-6 geometry L=[700,300], 700x300 grid, order [15,8] (the notebook's own order) or [25,25] (BASELINE.json's),
+    complex128, FoM = sum over the four polarisation pairs of |t_(1,0)|^2, gradient w.r.t. the density through the stabilised Eig."""
     lam = 532.
     eps_si = complex(asih_nk([lam])[0] ** 2)
     rho0 = torch.from_numpy(config5_density().astype(np.float64))
     out = {"eps_si": np.complex128(eps_si), "rho_sum": np.float64(rho0.sum()), "rho_sub": rho0[::70, ::30].numpy(), "lam": np.float64(lam)}
     torcwa.Eig.broadening_parameter = 1e-10
     rho = rho0.clone().requires_grad_(True)
-    sim = torcwa.rcwa(freq=1 / lam, order=[15, 8], L=[700., 300.], dtype=torch.complex128, device=torch.device("cpu"), stable_eig_grad=True)
+    sim = torcwa.rcwa(freq=1 / lam, order=list(order), L=[700., 300.], dtype=torch.complex128, device=torch.device("cpu"), stable_eig_grad=True)
     sim.add_input_layer(eps=1.46 ** 2)
     sim.set_incident_angle(inc_ang=0., azi_ang=0.)
     sim.add_layer(thickness=300., eps=rho * eps_si + (1. - rho))
@@ -449,13 +449,44 @@ def main_config5():
                **{f"t1{p}": t.detach().numpy() for p, t in ts.items()})
     lam2 = sim.kz_norm[0].detach().numpy() ** 2
     out["L0_kz2_sorted"] = lam2[np.lexsort((lam2.imag, lam2.real))]
-    np.savez_compressed(os.path.join(HERE, "config5_o15_8_c128.npz"), **out)
-    print("config5_o15_8: FoM", float(fom), "sum grad", gr.sum(), "|grad|", np.linalg.norm(gr))
+    out["order"] = np.array(order)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, ": FoM", float(fom), "sum grad", gr.sum(), "|grad|", np.linalg.norm(gr))
 
 
 if __name__ == "__main__" and "--fullsize" in sys.argv:
     sel = [a for a in sys.argv[1:] if a.startswith("config")] or ["config2", "config3", "config4", "config5"]
     main_fullsize(sel)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# configs 3 and 5 at BASELINE.json's OWN Fourier orders ([21,21]: n = 3698; [25,25]: n = 5202) -- one-off runs of the reference
+# (about 15 and 40 minutes on the 8-core build container):  python tests/golden/make_golden.py --fullorder [config3] [config5]
+# ---------------------------------------------------------------------------------------------------------
+def main_fullorder(which):
+    import time
+    if "config3" in which:
+        # the throughput stack of config 3 (bench.py:make_inputs_stack): four 200 nm layers, the 180 x 100 rectangle rotated by
+        # 0 / 30 / 60 / 90 degrees in SU-8, glass input; one wavelength of the 64-point sweep (index 33 of the 128-entry table)
+        t0 = time.time()
+        g32 = ref_geometry(300, 300, 300., 300., torch.float32)
+        lam = float(np.linspace(400., 700., 128)[66])
+        lays = []
+        for th in (0., 30., 60., 90.):
+            r = g32.rectangle(Wx=180., Wy=100., Cx=150., Cy=150., theta=th / 180 * np.pi)
+            lays.append((200., _grid_c64(r, _eps_si_c64(lam), 1.6 ** 2), 1.0))
+        run_case("config3_o21_l%d" % int(lam), freq=1 / lam, order=[21, 21], L=[300., 300.], dtype="c128f32", tag="c128f32",
+                 layers=lays, eps_in=1.46 ** 2, extra=lambda sim, lam=lam: {"lam": np.float64(lam)})
+        print("config3 at [21,21]: %.0f s" % (time.time() - t0))
+    if "config5" in which:
+        t0 = time.time()
+        main_config5(order=(25, 25), name="config5_o25_c128")
+        print("config5 at [25,25]: %.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__" and "--fullorder" in sys.argv:
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    main_fullorder([a for a in sys.argv[1:] if a.startswith("config")] or ["config3", "config5"])
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -206,6 +206,22 @@ def test_eig_multiple_bulge_chains(backend, chains):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("parts,dtype,tol", [(2, np.complex128, 1e-13), (3, np.complex64, 5e-6), (4, np.complex128, 1e-13)])
+def test_eig_hessenberg_sub_batches(backend, parts, dtype, tol):
+    """Knob hess_split: the Hessenberg reduction of a batch as 2 - 4 sub-batches on pooled side streams, each starting when the one before
+    has left the column loop of its first panel (default from 16 matrices on: two).  Uneven split (5 matrices), same result gates."""
+    be = get_backend(backend)
+    n = 70 if backend == "emu" else 300
+    A = (RNG.standard_normal((5, n, n)) + 1j * RNG.standard_normal((5, n, n))).astype(dtype)
+    try:
+        _set_knobs(be, hess_split=parts, eig_vec=1)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, hess_split=0, eig_vec=0)
+    check(A, w, V, info, tol)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_eig_nonfinite_input_fails_fast(backend):
     """A NaN in the input cannot converge: info reports the failure (LAPACK style) instead of iterating to the sweep limit."""
     be = get_backend(backend)
@@ -271,8 +287,8 @@ def test_eig_mixed_precision_route(backend, steps):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_eig_mixed_precision_fallback(backend):
-    """Coupled clusters: a triple eigenvalue is diagonalised exactly inside the refinement (small dense solver); a ten-fold one is beyond
-    it -- the matrix is flagged and the batch is redone by the all-fp64 pipeline.  Same result quality either way, no error."""
+    """Coupled clusters: a triple and a ten-fold eigenvalue are diagonalised exactly inside the refinement (small dense solver, clusters of up
+    to 32 members; rounds 3 - 5 stopped at 8 and redid the ten-fold case in fp64).  Same result quality either way, no error."""
     be = get_backend(backend)
     n = 40 if backend == "emu" else 300
     Q, _ = np.linalg.qr(RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)))
@@ -405,7 +421,7 @@ def test_eig_opts_two_threads():
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_eig_partial_fallback_is_per_matrix(backend):
-    """A batch in which ONE matrix has a ten-fold eigenvalue (beyond the refinement's exact cluster treatment): the mixed route keeps its
+    """A batch in which ONE matrix has a 36-fold eigenvalue (beyond the refinement's exact cluster treatment): the mixed route keeps its
     refined results for the other matrices and redoes only the flagged one in fp64, as a compact sub-batch inside the same workspace
     (trx_eig_last_fallback = number of matrices redone, on the calling thread).  No host-side route memory: the same call sequence in any
     order gives the same answers, and a batch without hard matrices reports 0 right after one with."""
@@ -417,7 +433,7 @@ def test_eig_partial_fallback_is_per_matrix(backend):
     rng = np.random.default_rng(5)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
     lam = 2.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
-    lam[:10] = 1.5 - 0.5j
+    lam[:36] = 1.5 - 0.5j                             # beyond the exact treatment (clusters of up to 32 members)
     hard = (Q * lam[None, :]) @ Q.conj().T
     A = (rng.standard_normal((6, n, n)) + 1j * rng.standard_normal((6, n, n))).astype(np.complex128)
     A[4] = hard                                         # 1 of 6 flagged: sub-batch of one
@@ -437,6 +453,16 @@ def test_eig_partial_fallback_is_per_matrix(backend):
         assert be.lib.eig_last_fallback() == 6
         for b in range(6):
             assert info[b] == 0 and np.abs(A2[b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A2[b]).max() < 1e-12, b
+        # a 20-fold eigenvalue is INSIDE the exact cluster treatment (diagonalised by the small dense solver): nothing is redone
+        lam3 = 2.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        lam3[:20] = -0.7 + 1.1j
+        A3 = A.copy()
+        A3[4] = (Q * lam3[None, :]) @ Q.conj().T
+        w, V, info = run_eig(be, A3)
+        assert be.lib.eig_last_fallback() == 0
+        for b in range(6):
+            assert info[b] == 0 and np.abs(A3[b] @ V[b] - V[b] * w[b][None, :]).max() / np.abs(A3[b]).max() < 1e-12, b
+        assert np.linalg.cond(V[4]) < 1e6
         At = torch.from_numpy(A).to(eng.device) if backend == "gpu" else None
         if At is not None:                           # the engine reports the same count and keeps no route state
             eng.eig(At)

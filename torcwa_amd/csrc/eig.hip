@@ -43,10 +43,10 @@ int eig_set_knob(const char* key, int value) {
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 static size_t eig_ws_bytes_f32(int n, int batch) { return eig_ws_bytes_t<float>(n, batch); }
 
-// Mixed route, on top of the all-fp64 layout: Z doubles as the second eigenvector buffer and X as G, which the update matrix (I + F) R then
-// overwrites in place; extra: pivots / flags / cluster tables / the saved diagonal + whatever the fp32 pool (A32, the fp32 eigensolver's own
-// workspace, V32, w32) needs beyond Z | X, which it overlaps: the pool is dead before the refinement first writes them, except V32 / w32,
-// which sit at its END (behind Z in any case: the first conversion may write Z while it reads them).
+// Mixed route, on top of the all-fp64 layout: Z holds the fp32 LU of the fp32 start and the fp32 correction matrix E, X the fp64 residual
+// A V (then F); extra: pivots / flags / coupling graph / cluster tables / the saved diagonal +
+// whatever the fp32 pool (A32, the fp32 eigensolver's own workspace, V32, w32) needs beyond Z | X, which it overlaps: the pool is dead before
+// the refinement first writes them, except V32 / w32, which sit at its END (behind Z in any case; they are consumed before X is written).
 static size_t mixed_pool_bytes(int n, int batch) {
     const size_t B = batch, N = n;
     return al256(8 * B * N * N) + al256(eig_ws_bytes_f32(n, batch)) + al256(8 * B * N * N) + al256(8 * B * N);
@@ -56,7 +56,8 @@ static size_t mixed_extra_bytes(int n, int batch) {
     const size_t zx = 2 * al256(e * B * N * N), pool = mixed_pool_bytes(n, batch);
     size_t tot = 0;
     if (pool > zx) tot += al256(pool - zx);                                    // spill of the fp32 pool beyond Z | X
-    tot += al256(sizeof(int) * B * N) * 2 + al256(sizeof(int) * (B + 1)) * 2 + al256(8 * B) * 2 + al256(8 * 64 * B) + al256(REFINE_CLUSTER_BYTES * B) + al256(e * B * N);
+    tot += al256(sizeof(int) * B * N) * 3 + al256(sizeof(int) * (B + 2)) * 2 + al256(sizeof(int) * B) + al256(sizeof(int) * 2 * REFINE_EDGE_CAP * B) +
+           al256(8 * B) * 2 + al256(8 * 64 * B) + al256(REFINE_CLUSTER_BYTES * B) + al256(e * B * N);
     return tot;
 }
 
@@ -123,19 +124,22 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.bal_flags = (int*)take(sizeof(int) * 2 * B);
     Bf.st = (QrState*)take(sizeof(QrState) * B);
     Bf.summary = (int*)take(sizeof(int) * 128 + sizeof(long long) * 24);  // up to 8 iteration groups x 16 ints
-    Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = nullptr;
+    Bf.r_piv = Bf.r_linfo = Bf.r_flags = Bf.r_partner = Bf.r_clus = Bf.r_edges = Bf.r_ecount = nullptr;
     Bf.r_eoff = Bf.r_lmax = Bf.r_scan = nullptr;
-    Bf.r_pairX = nullptr;
+    Bf.r_tab = nullptr;
     Bf.r_d0 = nullptr;
     if (eig_uses_mixed(n, batch, sizeof(T))) {
         Bf.r_piv = (int*)take(sizeof(int) * B * N);
         Bf.r_partner = (int*)take(sizeof(int) * B * N);
-        Bf.r_linfo = (int*)take(sizeof(int) * (B + 1));
-        Bf.r_flags = (int*)take(sizeof(int) * (B + 1));
+        Bf.r_clus = (int*)take(sizeof(int) * B * N);
+        Bf.r_linfo = (int*)take(sizeof(int) * (B + 2));
+        Bf.r_flags = (int*)take(sizeof(int) * (B + 2));
+        Bf.r_ecount = (int*)take(sizeof(int) * B);
+        Bf.r_edges = (int*)take(sizeof(int) * 2 * REFINE_EDGE_CAP * B);
         Bf.r_eoff = (T*)take(8 * B);
         Bf.r_lmax = (T*)take(8 * B);
         Bf.r_scan = (T*)take(8 * 64 * B);
-        Bf.r_pairX = (cx<T>*)take(REFINE_CLUSTER_BYTES * B);
+        Bf.r_tab = take(REFINE_CLUSTER_BYTES * B);
         Bf.r_d0 = (cx<T>*)take(e * B * N);
     }
 }
@@ -241,8 +245,10 @@ int eig_t(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info,
             rc = eig_t<float>(s, A32, w32, V32, n, batch, B.r_linfo, ws32, eig_ws_bytes_f32(n, batch));      // its info reaches eig_refine in R.linfo and is folded into the flags there
             if (rc) return rc;
             RefineBuffers<T> R;
-            R.G = B.X; R.d0 = B.r_d0; R.V1 = B.Z; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags; R.eoff = B.r_eoff; R.lmax = B.r_lmax; R.scan_part = B.r_scan;
-            R.partner = B.r_partner; R.pairX = B.r_pairX; R.clus = B.r_piv;
+            // Z (dead A32 / Z32 of the fp32 solve by now) takes the LU of the fp32 start and E; X takes the fp64 residual.  V32 lies at the END of
+            // the pool (behind Z, inside X and the spill): it is copied / converted before X is first written.
+            R.Rb = B.X; R.LU32 = (cx<float>*)B.Z; R.E32 = R.LU32 + Bn * N * N; R.d0 = B.r_d0; R.piv = B.r_piv; R.linfo = B.r_linfo; R.flags = B.r_flags;
+            R.eoff = B.r_eoff; R.lmax = B.r_lmax; R.scan_part = B.r_scan; R.partner = B.r_partner; R.clus = B.r_clus; R.edges = B.r_edges; R.ecount = B.r_ecount; R.tab = B.r_tab;
             int any = 0;
             std::vector<int> bad(batch, 0);
             // a failed fp32 solve shows up as non-finite input of the refinement (flag 1)
@@ -367,6 +373,7 @@ extern "C" int trx_tuning(const char* key, int value) {
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::refine_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::hess_set_knob(key, value);
     return rc;
 }
 

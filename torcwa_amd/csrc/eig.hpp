@@ -64,29 +64,33 @@ struct EigBuffers {
     // mixed-precision route (fp64 only; null otherwise)
     char* mixed_pool;          // fp32 pool = Z | X | spill
     size_t mixed_pool_bytes;
-    int *r_piv, *r_linfo, *r_flags, *r_partner;
+    int *r_piv, *r_linfo, *r_flags, *r_partner, *r_clus, *r_edges, *r_ecount;
     T *r_eoff, *r_lmax, *r_scan;
-    cx<T>* r_pairX;
-    cx<T>* r_d0;               // [B,n] diagonal of G
+    void* r_tab;
+    cx<T>* r_d0;               // [B,n] Lambda + diag E
 };
 
-// buffers of the mixed-precision route (eig_refine.hip): fp32 eigendecomposition + Newton refinement in fp64
+// buffers of the mixed-precision route (eig_refine.hip): fp32 eigendecomposition + Newton refinement to fp64
 template <class T>
 struct RefineBuffers {
-    cx<T>* G;        // [B,n,n]  A V, then V^-1 A V, then (in place) the update matrix (I + F) R
-    cx<T>* d0;       // [B,n]    diagonal of V^-1 A V (the in-place build overwrites it in G)
-    cx<T>* V1;       // [B,n,n]  second eigenvector buffer (LU copy, then the next iterate)
-    int* piv;        // [B,n]
-    int* linfo;      // [B]
-    int* flags;      // [B + 1]  per matrix: 1 = off-diagonal part not small, 2 = a cluster the exact treatment does not take; [B] = any flag or LU failure
-    T* eoff;         // [B] max off-diagonal |G_ij|
-    T* lmax;         // [B] max |G_ii|
-    T* scan_part;    // [B, 2 * 32] partial maxima of the scan (its workgroups per matrix)
-    int* partner;    // [B,n]
-    cx<T>* pairX;    // [B] cluster tables (RefineClusters<T>, REFINE_CLUSTER_BYTES each)
-    int* clus;       // [B,n]  256 * cluster + position, or -1 (aliases piv: the pivots are dead once the step's solve is done)
+    cx<T>* Rb;          // [B,n,n]  fp64: A V; once the residual has been taken from it: F
+    cx<float>* LU32;    // [B,n,n]  LU factors of the fp32 start V0 (factored once, used by every step)
+    cx<float>* E32;     // [B,n,n]  fp32(A V - V Lambda) -> E = V0^-1 (.); once F has been built from it: the product V F, one column block (fp64) at a time
+    cx<T>* d0;          // [B,n]    Lambda + diag E of the step (the eigenvalue array itself is overwritten for cluster members)
+    int* piv;           // [B,n]    pivots of LU32
+    int* linfo;         // [B]      info of the fp32 eigensolve on entry, then of the LU
+    int* flags;         // [B + 1]  per matrix: 1 = off-diagonal part not small / fp32 solve failed / V0 singular, 2 = a cluster the exact treatment does not take; [B] = count of flagged matrices, [B + 1] = clusters rotated in the running step
+    T* eoff;            // [B] max off-diagonal |E_ij|
+    T* lmax;            // [B] max |lambda_i|
+    T* scan_part;       // [B, 2 * 32] partial maxima of the scan (its workgroups per matrix)
+    int* partner;       // [B,n]    1 = index is coupled to another one
+    int* clus;          // [B,n]    RCM * cluster + position, or -1
+    int* edges;         // [B, REFINE_EDGE_CAP, 2] coupled pairs
+    int* ecount;        // [B]
+    void* tab;          // [B] cluster tables (RefineClusters<T>, REFINE_CLUSTER_BYTES each)
 };
-constexpr size_t REFINE_CLUSTER_BYTES = 280 * 1024;
+constexpr size_t REFINE_CLUSTER_BYTES = 1728 * 1024;
+constexpr int REFINE_EDGE_CAP = 16384;
 template <class T> int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const cx<float>* V32, const cx<float>* w32, cx<T>* w, cx<T>* V,
                                   int n, int batch, int steps, int* host_any, int* host_bad);
 int refine_set_knob(const char* key, int value);
@@ -95,11 +99,17 @@ int refine_steps();
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, int batch);
 
+// a non-blocking stream + timing-less events from the process-wide pool of eig_qr.hip (checked out for the duration of one call)
+struct SideStream { hipStream_t s = nullptr; hipEvent_t ev = nullptr, ev2 = nullptr, ev3 = nullptr; int* hsum = nullptr; int dev = -1; };
+bool side_stream_checkout(SideStream& out);
+void side_stream_return(const SideStream& in);
+
 template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 // Schur form: T in A, unitary accumulated into Z
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
 int qr_set_knob(const char* key, int value);
+int hess_set_knob(const char* key, int value);
 int eig_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 // V <- D V (undo of the balancing) with unit 2-norm columns

@@ -1457,6 +1457,21 @@ static void lane_return(const QrLane& l) {
     g_lane_free.push_back(l);
 }
 
+// A pooled side stream + event for the other stages of trx_eig (sub-batches of the Hessenberg reduction): same pool, same rules.
+bool side_stream_checkout(SideStream& out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    QrLane l;
+    if (!lane_checkout(dev, true, l)) return false;
+    out.s = l.s; out.ev = l.ev; out.ev2 = l.evs[0]; out.ev3 = l.evs[1]; out.hsum = l.hsum; out.dev = l.dev;
+    return true;
+}
+void side_stream_return(const SideStream& in) {
+    QrLane l;
+    l.s = in.s; l.ev = in.ev; l.evs[0] = in.ev2; l.evs[1] = in.ev3; l.hsum = in.hsum; l.dev = in.dev; l.has_stream = true;
+    lane_return(l);
+}
+
 // trx_tuning(): the environment variables only provide the defaults (read once); this sets a knob explicitly.  0 = automatic.
 int qr_set_knob(const char* key, int value) {
     QrKnobs& k = qr_knobs();
