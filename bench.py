@@ -66,6 +66,9 @@ def parse_args(argv=None):
                     "fits into the free HBM with 10 %% headroom, torcwa_amd.sweep.auto_chunk)")
     ap.add_argument("--cyclic", action="store_true", help="config 4, N > 1: rank r solves points r, r + N, ... instead of a contiguous block (SURVEY.md 8(e))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
+    ap.add_argument("--cu-reserve", type=int, default=0, help="with --streams > 1: compute units (spread over the XCDs) the chunk streams leave to the eigensolver's latency-bound kernels")
+    ap.add_argument("--cu-order", default="interleaved", choices=["interleaved", "xcdmajor"], help="bit order of the driver's CU mask (tests/micro/cumask_probe.hip)")
+    ap.add_argument("--cu-lanes", default="free", choices=["free", "reserved"], help="the library's internal streams: unrestricted, or restricted to the reserved CUs")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--eig-route", default="auto", choices=["auto", "mixed", "fp64"], help="eigensolver route of the sweep drivers (torcwa_amd.sweep.solve_stack_sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,9 +197,11 @@ def run_step(freq, grids, order, engine, args, chunk):
         return run_step_topopt(grids, order, engine)
     if args.config == 3:
         return solve_stack_sweep(freq, grids, order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64, precision=args.precision, engine=engine,
-                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False, eig_route=args.eig_route)
+                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False, eig_route=args.eig_route,
+                                 cu_reserve=args.cu_reserve, cu_order=args.cu_order, cu_lanes=args.cu_lanes)
     return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
-                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False, eig_route=args.eig_route)
+                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False, eig_route=args.eig_route,
+                                    cu_reserve=args.cu_reserve, cu_order=args.cu_order, cu_lanes=args.cu_lanes)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -342,7 +347,7 @@ def eig_is_mixed(args, n, chunk):
 
 
 def read_prof_tags(engine):
-    """{tag name: (launches, timed launches, flops of the timed, bytes of the timed, ms of the timed, flops over all launches)} for every tag
+    """{tag name: (launches, timed launches, flops of the timed, bytes of the timed, ms of the timed, flops over ALL launches, bytes over ALL launches)} for every tag
     libtrx instruments (kernel tags and the wall-clock phase tags of trx_eig)."""
     import ctypes
     out = {}
@@ -350,7 +355,7 @@ def read_prof_tags(engine):
         name = engine.lib.prof_tag_name(tag).decode()
         if name == "?":
             break
-        buf = (ctypes.c_double * 6)()
+        buf = (ctypes.c_double * 7)()
         engine.lib.check(engine.lib.prof_get(tag, ctypes.addressof(buf)))
         out[name] = tuple(buf)
     return out
@@ -379,7 +384,7 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
     """Live figures from the HIP events libtrx recorded (on the launch streams, uniformly sampled) during the timed region."""
     tags = read_prof_tags(engine)
     kernels = []
-    for name, (launches, timed, flops_t, bytes_t, ms, flops_all) in tags.items():
+    for name, (launches, timed, flops_t, bytes_t, ms, flops_all, bytes_all) in tags.items():
         if name.startswith("phase:") or timed <= 0 or ms <= 0:          # phases: see phase_table; not launched, or no usable event timing (CPU emulator)
             continue
         fp32_kernel = name.endswith("fp32") or args.precision == "native" or (name in _EIG_STAGE and eig_is_mixed(args, n, chunk))
@@ -396,10 +401,15 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
                           "unitary issues 13/16 of them); the iteration groups of the QR phase run their kernels concurrently on their own streams, so a "
                           "launch's event time includes the share of the GPU the others take")
         elif bound == "mfma" and flops_t > 0:
+            # achieved: work of the SAMPLED launches / their event time.  Work per launch (what is scaled to the step and held against the
+            # committed profiles): the EXACT mean over all launches -- a tag mixes a few 7 TFLOP calls with a thousand small ones, and which of
+            # the big ones the sampling stride hits moved the sampled mean by 7 % between a 3-step and a 20-step run
             k.update(bound="mfma", achieved=flops_t / (ms * 1e-3) / 1e12, peak=peak_tf, unit="TFLOP/s",
-                     algorithmic_flops_per_launch=flops_t / timed, algorithmic_bytes_per_launch=bytes_t / timed)
+                     algorithmic_flops_per_launch=flops_all / launches, algorithmic_bytes_per_launch=bytes_all / launches,
+                     sampled_flops_per_launch=flops_t / timed)
         elif bound == "hbm" and bytes_t > 0:
-            k.update(bound="hbm", achieved=bytes_t / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_launch=bytes_t / timed)
+            k.update(bound="hbm", achieved=bytes_t / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_launch=bytes_all / launches,
+                     sampled_bytes_per_launch=bytes_t / timed)
         elif bound == "latency":
             m = _LATENCY_MODEL[name]
             steps_per_launch = (flops_all / launches) if m["steps"] == "device" else m["steps"]
@@ -435,22 +445,28 @@ def roofline(engine, args, elapsed, steps, n, units_per_step, chunk=128):
             dom["traffic"] / 1e9, 1e3 * t_hbm, 1e3 * t_mfma, dom["traffic"] / max(dom.get("algorithmic_bytes_per_launch", 0.0), 1.0))
     t_meas = 1e3 * elapsed / (steps * units_per_step)
     roofs = layer_solve_roof(n, args.precision)
-    dom["layer_solve"] = {
+    layer = {
         "t_measured_ms": t_meas, "definition": "SURVEY.md 8(d): T_roof / T_measured per patterned layer-solve, nominal 260 n^3 flops + n^3/3 element reads",
         "t_roof_ms_at_fp32_peak": roofs["survey_fp32"], "frac_at_fp32_peak": roofs["survey_fp32"] / t_meas,
         "t_roof_ms_at_fp64_peak": roofs["fp64"], "frac_at_fp64_peak": roofs["fp64"] / t_meas,
         "priced_at": "fp64 (78.6 TF, 16-byte elements): the path delivers complex128 results (DESIGN.md section 3; S-matrix algebra and eigen-refinement "
                      "in fp64, the first stage of the mixed-precision eigensolver in fp32); the survey's own figure prices the same flops at the fp32 peak"
                      if args.precision == "high" else "fp32 (157.3 TF, 8-byte elements)"}
-    dom["kernels"] = kernels
     ph = phase_table(tags, engine.phase_report(), elapsed, steps)
-    dom["phases"] = ph
     red = sum(r["share_of_step"] for r in ph["phases"] if r["phase"].startswith("Redheffer"))
-    dom["redheffer_share_of_step"] = red
-    return dom
+    # HEADLINE = the figure the target is defined on: the whole patterned layer-solve against its roofline, priced as the survey
+    # wrote it -- 260 n^3 nominal real flops at the fp32 matrix peak (its eigensolver term is flop-bound there: 100 n^3 / 157.3 TF > the n^3 / 3
+    # element stream at 8 TB/s), so T_roof / T_measured = (260 n^3 / T_measured) / 157.3 TF.  The dominant kernel is a sub-field.
+    nominal_tf = 260.0 * float(n) ** 3 / (t_meas * 1e-3) / 1e12
+    head = {"bound": "mfma", "achieved": nominal_tf, "peak": PEAK_TFLOPS["native"], "unit": "TFLOP/s", "frac": layer["frac_at_fp32_peak"],
+            "traffic": dom["traffic"], "traffic_note": "of the dominant kernel, per call: " + str(dom["traffic_note"]),
+            "scope": "one patterned layer-solve (conv-matrix + P,Q + eig + layer S-matrix + its Redheffer product), SURVEY.md 8(d): achieved = 260 n^3 nominal "
+                     "real flops / measured time per layer-solve; frac = T_roof / T_measured = %.1f ms / %.1f ms" % (roofs["survey_fp32"], t_meas),
+            "layer_solve": layer, "dominant_kernel": dom, "kernels": kernels, "phases": ph, "redheffer_share_of_step": red}
+    return head
 
 
-PROFILE_TAG = "r05"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
+PROFILE_TAG = "r06"          # the committed profiles of this round: profiles/<tag>_kernel_profile.json, profiles/<tag>_pmc_bench.json
 
 
 def _tag_kernels(prof, name):
@@ -683,8 +699,8 @@ def main():
             "metric": "RCWA layer-solves/sec (complex64 I/O) at Fourier order [%d,%d]" % (args.order, args.order),
             "value": value, "unit": "layer-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "c128" if args.config == 5 else (("c128 results (mixed-precision eigensolver: fp32 eigendecomposition refined to fp64 by two Newton steps of fp64 GEMMs + LU; "
-                                                        "everything else fp64 MFMA); complex64 I/O" if eig_is_mixed(args, n, chunk) else "c128 arithmetic (fp64 MFMA; complex64 I/O)")
+            "dtype": "c128" if args.config == 5 else (("c128 results (mixed-precision eigensolver: fp32 eigendecomposition refined to fp64 by two Newton steps -- fp64 residual and update GEMMs, "
+                                                        "the correction solved with ONE fp32 LU of the fp32 start; everything else fp64 MFMA); complex64 I/O" if eig_is_mixed(args, n, chunk) else "c128 arithmetic (fp64 MFMA; complex64 I/O)")
                                                        if args.precision == "high" else "c64"),
             "data": "synthetic" if not EMU else "synthetic -- CPU kernel-logic EMULATOR, launcher plumbing test, not a measurement",
             "config": {"workload": wl, "points_total": int(total), "points_per_gpu": int(len(idx)), "layer_solves_per_point": layers_per_point,

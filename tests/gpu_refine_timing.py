@@ -22,7 +22,7 @@ for vec, steps in ((1, 0), (3, 1), (3, 2), (3, 3)):
     res = ((A0[:2] @ V[:2] - V[:2] * w[:2, None, :]).abs().max() / A0[:2].abs().max()).item()
     tags = []
     for tag in range(9):
-        buf = (ctypes.c_double * 6)(); L.prof_get(tag, ctypes.addressof(buf))
+        buf = (ctypes.c_double * 7)(); L.prof_get(tag, ctypes.addressof(buf))
         if buf[1] > 0: tags.append("%s %.0fms" % (L.prof_tag_name(tag).decode().split('<')[0][:14] + ('NN' if tag == 0 else ''), buf[4] / buf[1] * buf[0]))
     print(f"eig_vec {vec} steps {steps}: {t1-t0:.3f} s resid {res:.2e} fails {int((info!=0).sum())} ws {nws/2**30:.1f} GiB | " + ", ".join(tags), flush=True)
     del ws

@@ -4,11 +4,13 @@ Fixtures `tests/golden/config*_c128f32.npz` / `config5_o15_8_c128.npz` hold the 
 build container, `make_golden.py --fullsize`) run in complex128 on float32 / complex64-representable inputs:
 
   config 2  Example-1 rectangle, 1 layer, order [15,15] (n = 1922), lambda = 400 / 532 / 700 nm of the 128-point sweep
-  config 3  the literal 6-layer Example1-1 stack (3 rotated rectangles + 3 SU8 spacers), order [8,8], lambda = 650 / 500 nm
+  config 3  the literal 6-layer Example1-1 stack (3 rotated rectangles + 3 SU8 spacers), order [8,8], lambda = 650 / 500 nm; AND the throughput
+            stack of bench.py --config 3 (four patterned layers, rectangle rotated by 0 / 30 / 60 / 90 degrees in SU-8) at BASELINE.json's own
+            order [21,21] (n = 3698), one wavelength of the sweep (555.1 nm): `config3_o21_l555` (16 minutes of the reference on 8 cores)
   config 4  Example-3 style (Wx, Wy, lambda) grid, order [15,15]: a 2 x 2 x 2 sample of the 16^3 sweep, ALSO solved as one
             batch with per-point geometry (the batched sweep driver against the reference's per-point loop)
-  config 5  Example-6 geometry (L = [700,300], 700 x 300 grid), order [15,8], FoM = sum_pol |t_(1,0)|^2 and dFoM/d(density)
-            through the stabilised Eig backward
+  config 5  Example-6 geometry (L = [700,300], 700 x 300 grid), FoM = sum_pol |t_(1,0)|^2 and dFoM/d(density) through the stabilised Eig
+            backward: at the notebook's order [15,8] and at BASELINE.json's own [25,25] (n = 5202: `config5_o25_c128`, 13 minutes of the reference)
 
 Gates: complex128 run <= 1e-9, complex64-I/O run <= 1e-5 (north_star), gradient <= 1e-6 -- all against the reference's
 complex128 output on identical inputs.  `-m "not gpu"`: the CPU oracle is held to the same fixtures (pins the oracle at full size).
@@ -28,8 +30,9 @@ CONFIG4 = [c for c in FULL if c.startswith("config4")]
 
 
 def test_fixture_inventory():
-    assert len([c for c in FULL if c.startswith("config2")]) == 3 and len(CONFIG4) == 8 and len([c for c in FULL if c.startswith("config3")]) == 2
-    assert os.path.exists(os.path.join(GOLDEN, "config5_o15_8_c128.npz"))
+    assert len([c for c in FULL if c.startswith("config2")]) == 3 and len(CONFIG4) == 8 and len([c for c in FULL if c.startswith("config3")]) == 3
+    assert "config3_o21_l555" in FULL
+    assert os.path.exists(os.path.join(GOLDEN, "config5_o15_8_c128.npz")) and os.path.exists(os.path.join(GOLDEN, "config5_o25_c128.npz"))
 
 
 @pytest.mark.gpu
@@ -64,10 +67,11 @@ def test_config4_batched_geometry_sweep(dtype, tol):
 
 
 @pytest.mark.gpu
-def test_config5_fom_and_gradient():
+@pytest.mark.parametrize("order,fixture", [([15, 8], "config5_o15_8_c128.npz"), ([25, 25], "config5_o25_c128.npz")])
+def test_config5_fom_and_gradient(order, fixture):
     import torcwa_amd
     eng = make_engine("gpu")
-    g = np.load(os.path.join(GOLDEN, "config5_o15_8_c128.npz"))
+    g = np.load(os.path.join(GOLDEN, fixture))
     rho_np = config5_density().astype(np.float64)
     assert abs(rho_np.sum() - float(g["rho_sum"])) < 1e-6 and np.abs(rho_np[::70, ::30] - g["rho_sub"]).max() < 1e-12
     eps_si = complex(g["eps_si"])
@@ -75,7 +79,7 @@ def test_config5_fom_and_gradient():
     old = torcwa_amd.Eig.broadening_parameter
     torcwa_amd.Eig.broadening_parameter = 1e-10
     try:
-        sim = torcwa_amd.rcwa(freq=1 / float(g["lam"]), order=[15, 8], L=[700., 300.], dtype=torch.complex128, engine=eng, stable_eig_grad=True)
+        sim = torcwa_amd.rcwa(freq=1 / float(g["lam"]), order=order, L=[700., 300.], dtype=torch.complex128, engine=eng, stable_eig_grad=True)
         sim.add_input_layer(eps=1.46 ** 2)
         sim.set_incident_angle(inc_ang=0., azi_ang=0.)
         sim.add_layer(thickness=300., eps=rho * eps_si + (1. - rho))
@@ -107,7 +111,11 @@ def _oracle_case(g, dtype=torch.complex128):
     return orc, s, lays, S
 
 
-@pytest.mark.parametrize("name", ["config2_o15_l532", "config3_o8_l650"])
+SLOW = os.environ.get("TRX_SLOW_TESTS") == "1"
+
+
+@pytest.mark.parametrize("name", ["config2_o15_l532", "config3_o8_l650",
+                                  pytest.param("config3_o21_l555", marks=pytest.mark.skipif(not SLOW, reason="20 minutes of oracle time at n = 3698: TRX_SLOW_TESTS=1 (run once per round, profiles/r06_oracle_pin_o21.txt)"))])
 def test_oracle_pinned_at_full_size(name):
     from tests.helpers import DIRPORT, ORDERS_PROBE, POLS
     torch.set_num_threads(max(1, os.cpu_count() or 1))

@@ -120,6 +120,8 @@ def test_auto_chunk_fits_free_memory(monkeypatch):
     per = 18 * 3698 ** 2 * 16
     assert 8 <= c3 <= 64 and c3 * per <= (280 - 28.8) * gb
     assert sweep.auto_chunk(4096, [15, 15], 1, "native", dev) >= 2 * c4 - 8        # fp32 arithmetic: half the bytes
+    assert sweep.auto_chunk(4096, [15, 15], 1, "native", dev, dtype=torch.complex128) == c4          # a complex128 problem computes in complex128 whatever `precision` says
+    assert sweep.auto_chunk(4096, [15, 15], 1, "high", dev, streams=2) <= c4 // 2                     # two chunks are resident at once on two streams
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(30 * gb), int(288 * gb)))
     with pytest.raises(RuntimeError, match="needs about"):
         sweep.auto_chunk(64, [21, 21], 4, "high", dev)
@@ -153,6 +155,9 @@ def test_eig_route_policy_is_scoped_to_the_solver_or_sweep_call():
             self.calls.append(route)
             self.last_eig_fallback = self.next_fallback if route != 1 else 0
             return None, None
+
+        def eig_fallback_of_last_call(self):          # the per-thread count Engine.eig leaves behind (not the shared attribute)
+            return self.last_eig_fallback
 
     def solver(eng, route, hint):
         o = BatchedRCWA.__new__(BatchedRCWA)

@@ -391,7 +391,7 @@ class BatchedRCWA:
         if self.eig_route == "auto" and self._route_hint.get(key):
             route = 1
         lam, W = eng.eig(A, destroy=True, refine_steps=refine_steps, route=route)
-        if self.eig_route == "auto" and route == 0 and eng.last_eig_fallback > 0:
+        if self.eig_route == "auto" and route == 0 and eng.eig_fallback_of_last_call() > 0:
             self._route_hint[key] = True
         return lam, W
 

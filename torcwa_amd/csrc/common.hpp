@@ -192,6 +192,7 @@ void gemm_big_tile(int* bm, int* bn);
 int gemm_big(hipStream_t s, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
              int ldb, long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper);
 int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_big", 0 / 4)
+int lanes_set_cumask(const unsigned* mask, int words);  // eig_qr.hip: CU mask of the pooled internal streams
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
 
 // All-fp64 solve of the matrices bad[b] != 0 (nf of them) as ONE compact sub-batch inside the caller's workspace: the sub-batch's own buffers
 // (eig_carve for nf matrices) at the front, its input copies / outputs / index list at the tail.  TRX_ERR_WORKSPACE: no room (the caller then
-// redoes the whole batch).  bal_d: the scaling of the whole batch (its rows are gathered for the undo of the balancing).
+// redoes the whole batch).  bal_d: the scaling of the whole batch (its rows are gathered for the undo of the balancing).  Synchronises the
+// stream (host-side index list) and allocates host vectors: like the rest of trx_eig it cannot run under stream capture.
 template <class T>
 int eig_redo_subset(hipStream_t s, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, const T* bal_d, const std::vector<int>& bad, int nf) {
     const size_t e = sizeof(cx<T>), N = n, NF = nf;
@@ -199,6 +200,11 @@ int eig_redo_subset(hipStream_t s, void* A, void* w, void* V, int n, int batch, 
     int* idx = (int*)take(sizeof(int) * NF);
     int* isub = (int*)take(sizeof(int) * NF);
     p = p_save;
+    // The first gather reads the scaling rows of the WHOLE batch (bal_d, full-batch layout) and writes dsub; the sub-batch's big copies
+    // (Asub, Vsub) may lie over bal_d -- they are written AFTER that gather, on the same stream -- but the small pieces must not: they sit in
+    // what the refinement's tables occupied, behind bal_d in the layout.  Checked here instead of argued: no room -> the caller
+    // redoes the whole batch.
+    if ((const char*)wsub < (const char*)(bal_d + (size_t)batch * n)) return TRX_ERR_WORKSPACE;
     cx<T>* Asub = (cx<T>*)take(e * NF * N * N);
     cx<T>* Vsub = (cx<T>*)take(e * NF * N * N);
     std::vector<int> hidx;
@@ -384,14 +390,19 @@ extern "C" size_t trx_eig_ws_bytes(int dtype, int n, int batch) {
 
 extern "C" int trx_eig_last_fallback(void) { return trx::tl_last_fallback; }
 
+static inline bool eig_opts_valid(unsigned opts) {       // refine steps 0 - 4; route 0 (automatic), 1 (all one precision), 3 (mixed): 2 was the removed inverse-iteration route
+    const unsigned r = opts & 0xF, v = (opts >> 4) & 0xF;
+    return r <= 4 && (v == 0 || v == 1 || v == 3) && !(opts >> 8);
+}
+
 extern "C" size_t trx_eig_ws_bytes_opts(int dtype, int n, int batch, unsigned opts) {
-    if ((opts & 0xF) > 4 || ((opts >> 4) & 0xF) > 3 || (opts >> 8)) return 0;
+    if (!eig_opts_valid(opts)) return 0;
     trx::EigCallOpts guard(opts);
     return trx_eig_ws_bytes(dtype, n, batch);
 }
 
 extern "C" int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* info, void* ws, size_t ws_bytes, void* stream, unsigned opts) {
-    if ((opts & 0xF) > 4 || ((opts >> 4) & 0xF) > 3 || (opts >> 8)) return TRX_ERR_ARG;
+    if (!eig_opts_valid(opts)) return TRX_ERR_ARG;
     trx::EigCallOpts guard(opts);
     return trx_eig(dtype, A, w, V, n, batch, info, ws, ws_bytes, stream);
 }

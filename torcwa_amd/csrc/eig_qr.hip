@@ -1437,6 +1437,14 @@ struct QrLane {
 };
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
+// CU mask of the pooled streams (trx_lanes_cumask): empty = unrestricted.  Lanes are created on first use and kept, so the mask applies to
+// the lanes created after it was set (set it before the first trx_eig of the process).
+static std::vector<unsigned> g_lane_mask;
+int lanes_set_cumask(const unsigned* mask, int words) {
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    g_lane_mask.assign(mask, mask + (words > 0 ? words : 0));
+    return TRX_OK;
+}
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
     {
         std::lock_guard<std::mutex> lock(g_lane_mu);
@@ -1446,7 +1454,12 @@ static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
     out = QrLane();
     out.dev = dev;
     out.has_stream = want_stream;
-    if (want_stream && hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess) return false;
+    if (want_stream) {
+        std::vector<unsigned> mask;
+        { std::lock_guard<std::mutex> lock(g_lane_mu); mask = g_lane_mask; }
+        if (mask.empty() ? hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess
+                         : hipExtStreamCreateWithCUMask(&out.s, (unsigned)mask.size(), mask.data()) != hipSuccess) return false;
+    }
     if (hipEventCreateWithFlags(&out.ev, hipEventDisableTiming) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&out.evs[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&out.evs[1], hipEventDisableTiming) != hipSuccess) return false;
     if (hipHostMalloc((void**)&out.hsum, sizeof(int) * 8, hipHostMallocDefault) != hipSuccess) return false;

@@ -255,8 +255,18 @@ template <int OPA, int OPB, int WM, int WN, int QTM, int QTN>
 int launch_big(hipStream_t s, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B, int ldb, long sB,
                cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper) {
     typedef BigCfg<OPA, OPB, WM, WN, QTM, QTN> Cfg;
-    static std::once_flag attr_once;     // > 64 KB of dynamic LDS: opt in once per instantiation (host threads may race here)
-    std::call_once(attr_once, [] { (void)set_max_dyn_smem((const void*)gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>, Cfg::smem); });
+    // > 64 KB of dynamic LDS: opt in once per instantiation AND device (the attribute is per device; host threads may race here), and
+    // remember a failure so that no later call launches anyway
+    static std::mutex attr_mu;
+    static int attr_state[64];           // 0 = not yet set, 1 = ok, 2 = failed
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        int& st = attr_state[dev & 63];
+        if (st == 0) st = set_max_dyn_smem((const void*)gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>, Cfg::smem) ? 2 : 1;
+        if (st == 2) return TRX_ERR_LAUNCH;
+    }
     TRX_LAUNCH((gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>), dim3(cdiv_i(n, Cfg::QBN), cdiv_i(m, Cfg::QBM), batch), dim3(64 * Cfg::NW), Cfg::smem, s, m, n, k, alpha,
                A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
     TRX_CHECK_LAUNCH();

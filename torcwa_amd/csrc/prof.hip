@@ -92,7 +92,7 @@ extern "C" int trx_prof_reset(void) {
     return TRX_OK;
 }
 
-// out[6] = {launches, timed_launches, flops_timed, bytes_timed, ms_timed, flops_all}
+// out[7] = {launches, timed_launches, flops_timed, bytes_timed, ms_timed, flops_all, bytes_all}
 extern "C" int trx_prof_get(int tag, double* out) {
     if (tag < 0 || tag >= PROF_NTAGS || !out) return TRX_ERR_ARG;
     TagData& t = g_tags[tag];
@@ -105,7 +105,7 @@ extern "C" int trx_prof_get(int tag, double* out) {
         fl += t.sflops[i];
         by += t.sbytes[i];
     }
-    out[0] = t.launches; out[1] = t.used; out[2] = fl; out[3] = by; out[4] = ms; out[5] = t.flops;
+    out[0] = t.launches; out[1] = t.used; out[2] = fl; out[3] = by; out[4] = ms; out[5] = t.flops; out[6] = t.bytes;
     return TRX_OK;
 }
 

@@ -55,6 +55,7 @@ class Engine:
         self.check_info = True
         self._fail_acc = {}            # per host thread: device-side count of non-zero info entries seen while check_info is False
         self.last_eig_fallback = 0
+        self._tls = threading.local()
         self.profile_phases = False    # bench.py: event pairs around the phases of a layer-solve (see _phase)
         self._phase_events = []
 
@@ -188,9 +189,11 @@ class Engine:
         MI355X, one step is NOT enough for the 1e-5 gate of a complex64 problem at order [15,15] -- the fp32 start of this pipeline leaves
         max |E| ~ 2e-2 ... 2e-1 there).
         route: 0 = the library's automatic choice (mixed precision for complex128 input with n >= 256 and batch >= 8), 1 = all-fp64 (all-fp32 for
-        complex64 input), 3 = mixed wherever n >= 8 (include/trx.h "eig_vec").  After the call `last_eig_fallback` holds the number of matrices the
-        mixed route redid in fp64."""
+        complex64 input), 3 = mixed wherever n >= 8 (include/trx.h "eig_vec").  After the call `eig_fallback_of_last_call()` gives the number of
+        matrices the mixed route redid in fp64 (per calling thread)."""
         self._check(A)
+        if int(route) not in (0, 1, 3):
+            raise ValueError("eig route must be 0 (automatic), 1 (one precision) or 3 (mixed); 2 was the removed inverse-iteration route")
         opts = (int(refine_steps) & 0xF) | ((int(route) & 0xF) << 4)          # per-call option word of trx_eig_opts (no process-global knob is touched: thread-safe)
         # (No route policy lives here any more: matrices the mixed-precision route cannot certify -- clusters of close eigenvalues beyond the
         # refinement's exact treatment -- are redone in fp64 INSIDE the library, as a sub-batch; results do not depend on call history.)
@@ -203,9 +206,15 @@ class Engine:
         nws = self.lib.eig_ws_bytes_opts(_CODE[dt], n, B, opts)
         ws = self._ws(nws)
         self.lib.check(self.lib.eig_opts(_CODE[dt], A.data_ptr(), w.data_ptr(), V.data_ptr(), n, B, info.data_ptr(), ws.data_ptr(), nws, self.stream, opts))
-        self.last_eig_fallback = int(self.lib.eig_last_fallback())      # matrices of this call redone in fp64 (diagnostic; thread-local in the library)
+        fb = int(self.lib.eig_last_fallback())        # matrices of THIS call redone in fp64 (thread-local in the library: the calling thread's last trx_eig)
+        self._tls.eig_fallback = fb                   # per host thread: the solver that called reads its own call's count (eig_fallback_of_last_call)
+        self.last_eig_fallback = fb                   # diagnostic only: shared by every thread of a multi-stream sweep
         self._info(info, "eig")
         return w, V
+
+    def eig_fallback_of_last_call(self):
+        """Matrices the calling thread's last `eig` redid in fp64 (0 if this thread has not called it)."""
+        return getattr(self._tls, "eig_fallback", 0)
 
     @_phase("adjoint (eig backward, solves)")
     def eig_backward(self, w, V, gw, gV, broadening):

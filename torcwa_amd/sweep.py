@@ -99,14 +99,17 @@ _POINT_MATRICES = {1: 15.0, 2: 18.0}          # layers == 1 / layers >= 2 (what 
 _HEADROOM = 0.10                               # fraction of the device memory a sweep leaves free
 
 
-def auto_chunk(B, order, n_layers, precision, device):
+def auto_chunk(B, order, n_layers, precision, device, dtype=torch.complex64, streams=1):
     """Largest number of points solved in lock-step that fits the free HBM of `device` with _HEADROOM to spare (a multiple of 8 when it
     is cut: the mixed-precision eigensolver and its iteration groups want batches of at least 8).  Raises with the numbers when not even
     one point fits -- instead of an allocator error in the middle of a solve."""
     if device.type != "cuda":
         return B
     n = 2 * (2 * order[0] + 1) * (2 * order[1] + 1)
-    per_point = _POINT_MATRICES[1 if n_layers <= 1 else 2] * n * n * (16 if precision == "high" else 8)
+    # element size of the COMPUTE dtype: complex128 unless a complex64 problem is solved natively (BatchedRCWA: precision="native" only
+    # halves the element of complex64 problems); `streams` chunks are resident at once when the sweep is dealt to several streams
+    elem = 8 if (precision == "native" and dtype == torch.complex64) else 16
+    per_point = _POINT_MATRICES[1 if n_layers <= 1 else 2] * n * n * elem * max(1, int(streams))
     free, total = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the caching allocator's idle blocks are ours to reuse
     budget = free - _HEADROOM * total
@@ -128,9 +131,50 @@ def _slice(v, lo, hi, B):
     return v
 
 
+# ---- CU-partitioned streams (include/trx.h: trx_stream_create_cumask) -----------------------------------------------------------------------
+_MASKED = {}          # (device index, reserve, order) -> [torch.cuda.ExternalStream, ...]: created once, kept for the life of the process
+
+
+def cu_masks(n_cu, reserve, order="interleaved"):
+    """(throughput mask, reserved mask) as lists of 32-bit words over `n_cu` compute units: `reserve` CUs, spread evenly over the 8 XCDs, are
+    taken out of the throughput mask.  order = bit order of the driver's CU mask: "interleaved" (bit i = CU i // 8 of XCD i % 8: the
+    reserved CUs are bits [0, reserve)) or "xcdmajor" (bit i = CU i % 32 of XCD i // 32: bits 32 x + j, j < reserve / 8)."""
+    words = (n_cu + 31) // 32
+    res = [0] * words
+    per_xcd = max(1, reserve // 8)
+    for i in range(n_cu):
+        hit = (i < reserve) if order == "interleaved" else ((i % 32) < per_xcd)
+        if hit:
+            res[i // 32] |= 1 << (i % 32)
+    full = [(0xFFFFFFFF if 32 * (w + 1) <= n_cu else (1 << (n_cu - 32 * w)) - 1) for w in range(words)]
+    return [f & ~r & 0xFFFFFFFF for f, r in zip(full, res)], res
+
+
+def masked_streams(engine, dev, count, reserve, order="interleaved", lanes="free"):
+    """`count` HIP streams for the chunks of a sweep that leave `reserve` CUs to the latency-bound kernels of trx_eig (its pooled internal
+    streams: lanes = "free" -> unrestricted, they find the reserved CUs empty; "reserved" -> restricted to the reserved CUs)."""
+    import ctypes
+    key = (dev.index, count, reserve, order, lanes)
+    if key not in _MASKED:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        thr, res = cu_masks(n_cu, reserve, order)
+        arr = (ctypes.c_uint32 * len(thr))(*thr)
+        pool = []
+        for _ in range(count):
+            h = ctypes.c_void_p()
+            engine.lib.check(engine.lib.stream_create_cumask(ctypes.addressof(h), ctypes.addressof(arr), len(thr)))
+            pool.append(torch.cuda.ExternalStream(h.value, device=dev))
+        if lanes == "reserved":
+            rarr = (ctypes.c_uint32 * len(res))(*res)
+            engine.lib.check(engine.lib.lanes_cumask(ctypes.addressof(rarr), len(res)))
+        _MASKED[key] = pool
+    return _MASKED[key]
+
+
 def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0, dtype=torch.complex64,
                       precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),), polarization="xx",
-                      direction="forward", port="transmission", check_info=True, eig_route="auto"):
+                      direction="forward", port="transmission", check_info=True, eig_route="auto", cu_reserve=0, cu_order="interleaved",
+                      cu_lanes="free"):
     """B sweep points of a multi-layer stack (BASELINE.json configs 2-4): the reference's per-point Python loop
     (example/Example1-1.ipynb, Example3.ipynb) as chunks of a batched solve.  `layers` as in `_solve_chunk`, with
     per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)].
@@ -142,7 +186,7 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
     eng = engine if engine is not None else default_engine()
     old_check, eng.check_info = eng.check_info, check_info         # restored below: the engine may be shared with other solvers
     # chunk=None: as many points in lock-step as the free HBM holds (the reference's per-point loop cannot run out of memory; neither must this)
-    chunk = auto_chunk(B, order, len(layers), precision, freq.device) if not chunk else int(chunk)
+    chunk = auto_chunk(B, order, len(layers), precision, freq.device, dtype=dtype, streams=streams) if not chunk else int(chunk)
     if streams > 1 and chunk >= B:
         chunk = -(-B // streams)
     spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
@@ -157,21 +201,25 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
                                eig_route=eig_route, route_hint=route_hint)
 
     dev = freq.device
+    pool = None
+    if streams > 1 and cu_reserve > 0 and dev.type == "cuda" and len(spans) > 1:
+        pool = masked_streams(eng, dev, streams, cu_reserve, cu_order, cu_lanes)
     try:
-        _run_spans(run, spans, streams, dev)
+        _run_spans(run, spans, streams, dev, pool)
     finally:
         eng.check_info = old_check
     return torch.cat(outs, dim=0)
 
 
-def _run_spans(run, spans, streams, dev):
+def _run_spans(run, spans, streams, dev, pool=None):
     import threading
     if streams <= 1 or len(spans) == 1 or dev.type != "cuda":
         for i in range(len(spans)):
             run(i)
     else:
         cur = torch.cuda.current_stream(dev)
-        pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        if pool is None:
+            pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
         errors = []
 
         def worker(w):
@@ -200,7 +248,8 @@ def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
     chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default None = as many as the free HBM holds with
               10 % headroom, `auto_chunk`).  At order [15,15] (n = 1922) a point costs about 0.6 GB allocated / 0.9 GB reserved, so about 256 points
               fit the 288 GB of an MI355X, and larger chunks are faster (measured, round 5: 15.7 / 22.1 / 27.9 / 32.2 layer-solves/s at 16 / 32 / 64 / 128 points).
-    streams : number of HIP streams / host threads the chunks are dealt to (default 1: on MI355X one stream was measured
-              faster -- the QR window kernel needs 133 KB of LDS and evicts the slab workgroups of the other stream).
+    streams : number of HIP streams / host threads the chunks are dealt to (default 1).  With cu_reserve = K > 0 the streams are created with a
+              CU mask that leaves K compute units (K / 8 per XCD) to the latency-bound kernels of the eigensolver, so that a chip-filling GEMM
+              of one chunk cannot starve the QR chains of the other (profiles/r06_ab/cumask.txt).
     """
     return solve_stack_sweep(freq.to(eps_grids.device), [(thickness, eps_grids)], order, L, **kw)
