@@ -209,7 +209,7 @@ def test_eig_multiple_bulge_chains(backend, chains):
 @pytest.mark.parametrize("parts,dtype,tol", [(2, np.complex128, 1e-13), (3, np.complex64, 5e-6), (4, np.complex128, 1e-13)])
 def test_eig_hessenberg_sub_batches(backend, parts, dtype, tol):
     """Knob hess_split: the Hessenberg reduction of a batch as 2 - 4 sub-batches on pooled side streams, each starting when the one before
-    has left the column loop of its first panel (default from 16 matrices on: two).  Uneven split (5 matrices), same result gates."""
+    has left the column loop of its first panel (opt-in: measured slower than one batch on MI355X).  Uneven split (5 matrices), same result gates."""
     be = get_backend(backend)
     n = 70 if backend == "emu" else 300
     A = (RNG.standard_normal((5, n, n)) + 1j * RNG.standard_normal((5, n, n))).astype(dtype)

@@ -99,11 +99,6 @@ int refine_steps();
 template <class T> size_t eig_ws_bytes_t(int n, int batch);
 template <class T> void eig_carve(EigBuffers<T>& B, void* A, void* ws, int n, int batch);
 
-// a non-blocking stream + timing-less events from the process-wide pool of eig_qr.hip (checked out for the duration of one call)
-struct SideStream { hipStream_t s = nullptr; hipEvent_t ev = nullptr, ev2 = nullptr, ev3 = nullptr; int* hsum = nullptr; int dev = -1; };
-bool side_stream_checkout(SideStream& out);
-void side_stream_return(const SideStream& in);
-
 template <class T> int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch);
 // Schur form: T in A, unitary accumulated into Z

@@ -281,7 +281,7 @@ static int hess_rpw(int batch) {
     return v ? v : (batch >= 64 ? 2 : 4);
 }
 
-// Sub-batches of the reduction on their own streams (trx_tuning("hess_split", k) / TRX_HESS_SPLIT; 0 = automatic, 1 = off).  A panel is a
+// Sub-batches of the reduction on their own streams (trx_tuning("hess_split", k) / TRX_HESS_SPLIT; 0 / 1 = off: the default, see hessenberg()).  A panel is a
 // column loop bound by the HBM stream (gemv) and by one-workgroup latency (reflector), followed by GEMM-shaped block updates bound by the
 // matrix cores; run as ONE lock-step batch the two never overlap and HBM idles during every reflector kernel (10 % of the loop).  Two
 // sub-batches half a panel out of phase put one's block updates and reflector kernels under the other's stream.
@@ -383,9 +383,10 @@ static int hessenberg_sub(hipStream_t s, const EigBuffers<T>& B, int n, int batc
 
 template <class T>
 int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
-    // automatic: two sub-batches from 16 matrices on (each still fills the chip: 8 x 30 gemv workgroups), when the matrix is large enough
-    // for the stream to matter
-    int parts = g_hess_split ? g_hess_split : ((batch >= 16 && n >= 512) ? 2 : 1);
+    // Off unless asked for.  Measured on MI355X (profiles/r06_ab/r6a_first_call.txt, n = 1922): the Hessenberg phase of the 128-matrix
+    // step takes 882 ms as one batch and 914 / 946 / 1001 ms as 2 / 3 / 4 sub-batches (batch 16: 181 vs 217 ms) -- two chip-filling gemv
+    // grids do not overlap, they share the chip, and the reflector kernel of one queues behind the workgroups of the other.
+    int parts = g_hess_split > 1 ? g_hess_split : 1;
     if (parts > batch) parts = batch;
     if (parts <= 1) return hessenberg_sub<T>(s, B, n, batch, nullptr, nullptr);
     SideStream side[4];
