@@ -1081,22 +1081,42 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
         __syncthreads();
         if (dbg) { const long long t1 = clock64(); dbg[12] += t1 - tk0; tk0 = t1; }
+        // The window unitary U lives in REGISTERS: wave sb owns rows UR sb .. UR sb + UR - 1, lane = column.  A chain step multiplies U from
+        // the right by the step's rotations, which act on DISJOINT adjacent column pairs -- for a row held one column per lane that is one
+        // lane-parallel operation with the neighbour lane's value (v_mov_dpp wave_shl / wave_shr), every wave on its own rows, no barrier and
+        // no LDS traffic but the 12 - 24 bytes of the rotation itself.  (Rounds 2 - 5 replayed the logged rotations onto U in LDS after the
+        // chase: one more LDS round trip and one more 16-wave barrier per chain step, ~600 of the ~3800 cycles a chain step cost in all.)
+        constexpr int UR = QW / (WTHREADS / 64);
+        cx<T> u[UR];
+#pragma unroll
+        for (int i = 0; i < UR; ++i) u[i] = cx<T>((UR * sb + i == j) ? T(1) : T(0), T(0));
         // Every phase of a chain step touches WIT element pairs per lane: the loops are fully unrolled with clamped LDS reads issued
         // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
         // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
         // barrier absorbs the skew.)
+        // FORWARDED rotation inputs: the (f, g) of chain step tau + 1 are H[q + 1, q] and H[q + 2, q] -- column q, which this wave's OWN right
+        // rotation of step tau has just produced (rows q + 1, q + 2 = lanes q + 1, q + 2) and which no other bulge touches in between (their
+        // column pairs are disjoint from ours within a step, and left rotations came before).  So the next rotation is generated from
+        // registers (two v_readlane) in the shadow of the step's second barrier instead of an LDS round trip after it: 830 of the 2440
+        // cycles of a chain step were this read + generate (TRX_QR_DEBUG, profiles/r06_ab/r6a_first_call.txt).
+        static_assert(WIT == 1, "forwarding reads row q + 1 / q + 2 from lanes q + 1 / q + 2");
+        Rot<T> Rnext;
+        bool have_next = false;                       // (wave-uniform)
         for (int tau = tau0; tau <= tau_end; ++tau) {
             const int p = ilo + tau - 2 * sb;
             const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
             const int q = p - w0;
             const bool first = (p == ilo);
             Rot<T> R;
-            if (active) {
+            if (active && have_next) {
+                R = Rnext;
+            } else if (active) {
                 cx<T> f, g;
                 if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
                 else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
                 R = rotg_fast(f, g);
             } else { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0)); }
+            have_next = false;
             if (j == 0) { rlog[(tau - tau0) * QNS + sb].c = R.c; rlog[(tau - tau0) * QNS + sb].s = R.s; }
             wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
             if (dbg) { const long long t1 = clock64(); dbg[16] += t1 - tk0; tk0 = t1; }
@@ -1120,20 +1140,46 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             if (dbg) { const long long t1 = clock64(); dbg[17] += t1 - tk0; tk0 = t1; }
             __syncthreads();
             if (dbg) { const long long t1 = clock64(); dbg[18] += t1 - tk0; tk0 = t1; }
+            const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
+            cx<T> xh[WIT], yh[WIT];
             if (active) {
-                const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
-                cx<T> xh[WIT], yh[WIT];
 #pragma unroll
                 for (int it = 0; it < WIT; ++it) {
                     const int row = j + LPB * it;
                     const int rh = row <= hi ? row : hi;
                     xh[it] = Hw[rh * LD + q]; yh[it] = Hw[rh * LD + q + 1];
                 }
+            }
+            {
+                // U <- U G(tau): lane j = column j belongs to bulge sp = (q0 + 1 - j) >> 1 (q0 = bulge 0's column; first column of the pair when
+                // q0 + 1 - j is odd); the rotation comes from the log of this step (every wave has written its entry before the barrier;
+                // bulges that do not move logged the identity).  (x, y) <- (c x + conj(s) y, -s x + c y) for the pair (x, y) = (this lane,
+                // next lane) resp. (previous lane, this lane).
+                const int d = (ilo + tau - w0) + 1 - j;
+                const int sp = d >> 1;
+                const bool in = d >= 0 && sp < QNS;
+                RotCS<T> rc = rlog[(tau - tau0) * QNS + (in ? sp : 0)];
+                if (!in) { rc.c = T(1); rc.s = cx<T>(T(0), T(0)); }
+                const bool firstcol = (d & 1) != 0;
+                const cx<T> coef = firstcol ? conj(rc.s) : cx<T>(-rc.s.x, -rc.s.y);
+#pragma unroll
+                for (int i = 0; i < UR; ++i) {
+                    const cx<T> nx = lane_from_next(u[i]), pv = lane_from_prev(u[i]);
+                    const cx<T> partner = firstcol ? nx : pv;
+                    u[i] = rc.c * u[i] + coef * partner;
+                }
+            }
+            if (active) {
 #pragma unroll
                 for (int it = 0; it < WIT; ++it) {
                     const int row = j + LPB * it;
                     rot_cols(R, xh[it], yh[it]);
                     if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
+                }
+                if (q + 2 <= ww - 1 && p + 1 <= ihi - 1 && tau < tau_end) {
+                    // the bulge stays inside this window and inside the active block: its next rotation from the new column q
+                    Rnext = rotg_fast(bcast_lane(xh[0], q + 1), bcast_lane(xh[0], q + 2));
+                    have_next = true;
                 }
             }
             if (dbg) { const long long t1 = clock64(); dbg[19] += t1 - tk0; tk0 = t1; }
@@ -1143,70 +1189,35 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
         cx<T>* U = Ulog_all + (((long)b * nslot + slot0 + s) * kc + ch) * QW * QW;
         {
-            // phase 1 done: the window goes back to H, the buffer becomes U = I
+            // chase done: the window goes back to H (through registers: the planes of the band update take over its LDS)
             const int c = t & (QW - 1), r4 = t / QW;
             cx<T> hv[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
-            __syncthreads();
+            if (t == 0) *sflag = 0;
+            __syncthreads();                             // every thread holds its part of the window: the buffer may be overwritten (planes below)
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int r = r4 + RSTEP * i;
                 if (r < ww && c < ww) H[(long)(w0 + r) * n + w0 + c] = hv[i];
-                Hw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
             }
-        }
-        __syncthreads();
-        // phase 2: replay the logged rotations onto U (right multiplications; within a chain step the bulges own disjoint column pairs)
-        for (int tau = tau0; tau <= tau_end; ++tau) {
-            const int p = ilo + tau - 2 * sb;
-            const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
-            if (active) {
-                const int q = p - w0;
-                Rot<T> R;
-                R.c = rlog[(tau - tau0) * QNS + sb].c; R.s = rlog[(tau - tau0) * QNS + sb].s;
-                cx<T> xu[WIT], yu[WIT];
-#pragma unroll
-                for (int it = 0; it < WIT; ++it) {
-                    const int row = j + LPB * it;
-                    const int ru = row < ww ? row : ww - 1;
-                    xu[it] = Hw[ru * LD + q]; yu[it] = Hw[ru * LD + q + 1];
-                }
-#pragma unroll
-                for (int it = 0; it < WIT; ++it) {
-                    const int row = j + LPB * it;
-                    rot_cols(R, xu[it], yu[it]);
-                    if (row < ww) { Hw[row * LD + q] = xu[it]; Hw[row * LD + q + 1] = yu[it]; }
-                }
-            }
-            __syncthreads();
         }
         const bool do_band = band_e > w1;            // (workgroup-uniform)
         {
-            // U goes to the log; for the band update also, through registers, into split planes over the same LDS (zero outside ww x ww)
-            const int c = t & (QW - 1), r4 = t / QW;
-            cx<T> hv[RPT];
+            // U goes from the registers to the log; for the band update also into split planes over the window's LDS (zero outside ww x ww)
+            int dense = 0;
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
-            if (c < ww) {
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = r4 + RSTEP * i;
-                    if (r < ww) U[r * QW + c] = hv[i];
-                }
-            }
-            if (do_band) {
-                if (t == 0) *sflag = 0;
-                __syncthreads();                         // every thread holds its part of U; the buffer may be overwritten
-                int dense = 0;
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = r4 + RSTEP * i;
-                    cx<T> v = hv[i];
-                    if (r >= ww || c >= ww) v = cx<T>(T(0), T(0));
+            for (int i = 0; i < UR; ++i) {
+                const int r = UR * sb + i, c = j;
+                cx<T> v = u[i];
+                if (r < ww && c < ww) U[r * QW + c] = v;
+                else v = cx<T>(T(0), T(0));
+                if (do_band) {
                     Ur[r * MLD + c] = v.x; Ui[r * MLD + c] = v.y;
                     if ((r >> 4) >= (c >> 4) + 2 && (v.x != T(0) || v.y != T(0))) dense = 1;
                 }
+            }
+            if (do_band) {
                 if (dense) *sflag = 1;
                 __syncthreads();
             }
