@@ -66,9 +66,6 @@ def parse_args(argv=None):
                     "fits into the free HBM with 10 %% headroom, torcwa_amd.sweep.auto_chunk)")
     ap.add_argument("--cyclic", action="store_true", help="config 4, N > 1: rank r solves points r, r + N, ... instead of a contiguous block (SURVEY.md 8(e))")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (host threads) the chunks of a step are dealt to")
-    ap.add_argument("--cu-reserve", type=int, default=0, help="with --streams > 1: compute units (spread over the XCDs) the chunk streams leave to the eigensolver's latency-bound kernels")
-    ap.add_argument("--cu-order", default="interleaved", choices=["interleaved", "xcdmajor"], help="bit order of the driver's CU mask (tests/micro/cumask_probe.hip)")
-    ap.add_argument("--cu-lanes", default="free", choices=["free", "reserved"], help="the library's internal streams: unrestricted, or restricted to the reserved CUs")
     ap.add_argument("--precision", default="high", choices=["high", "native"])
     ap.add_argument("--eig-route", default="auto", choices=["auto", "mixed", "fp64"], help="eigensolver route of the sweep drivers (torcwa_amd.sweep.solve_stack_sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,11 +194,9 @@ def run_step(freq, grids, order, engine, args, chunk):
         return run_step_topopt(grids, order, engine)
     if args.config == 3:
         return solve_stack_sweep(freq, grids, order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64, precision=args.precision, engine=engine,
-                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False, eig_route=args.eig_route,
-                                 cu_reserve=args.cu_reserve, cu_order=args.cu_order, cu_lanes=args.cu_lanes)
+                                 chunk=chunk, streams=args.streams, orders=[(0, 0)], polarization="xx", check_info=False, eig_route=args.eig_route)
     return solve_single_layer_sweep(freq, grids, 300., order, [300., 300.], eps_in=1.46 ** 2, dtype=torch.complex64,
-                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False, eig_route=args.eig_route,
-                                    cu_reserve=args.cu_reserve, cu_order=args.cu_order, cu_lanes=args.cu_lanes)
+                                    precision=args.precision, engine=engine, chunk=chunk, streams=args.streams, check_info=False, eig_route=args.eig_route)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -189,19 +189,6 @@ size_t trx_build_a_ws_bytes(int dtype, int N, int batch);
 int trx_build_a(int dtype, const void* E, const void* Einv, const void* mu, const void* kx, const void* ky, int N, int batch, void* A,
                 void* ws, size_t ws_bytes, void* stream);
 
-/* ---- CU-partitioned streams (additive; no reference counterpart) ----------------------------------------------------------
- * A sweep solved as two half-batches on two host threads overlaps the latency-bound chains of one half (QR iteration, panel
- * factorisations: a few workgroups, most of the chip idle) with the chip-filling GEMM / gemv phases of the other -- provided a
- * long-running GEMM grid cannot occupy every CU, which it does on ordinary streams.  trx_stream_create_cumask returns a HIP
- * stream whose kernels run only on the compute units whose bits are set in mask[0 .. words) (hipExtStreamCreateWithCUMask; the
- * driver's bit order interleaves the XCDs: bit i = CU i / 8 of XCD i mod 8 on MI355X, tests/micro/cumask_probe.hip); the caller
- * makes it the current stream of its framework (torch.cuda.ExternalStream) and destroys it with trx_stream_destroy.
- * trx_lanes_cumask restricts the library's OWN pooled streams (iteration groups of trx_eig's QR phase, sub-batches of its
- * Hessenberg reduction) created after the call; words = 0 lifts the restriction.  Process-wide: call it before the first trx_eig. */
-int trx_stream_create_cumask(void** stream, const unsigned* mask, int words);
-int trx_stream_destroy(void* stream);
-int trx_lanes_cumask(const unsigned* mask, int words);
-
 /* ---- measurement aid (no reference counterpart): HIP-event timing of the dominant kernels --------------------
  * trx_prof_enable(1) makes the instrumented launch sites record hipEvents on the launch stream.  Sampling is systematic and
  * uniform over the run: every stride-th launch of a tag is timed; when the pool (2048 event pairs per tag) is full every

@@ -62,7 +62,6 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 // streams execute synchronously in the emulator: extra streams and cross-stream waits are no-ops
 static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
-inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }

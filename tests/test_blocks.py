@@ -271,34 +271,6 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("parts", [2, 3])
-def test_lu_sub_batches_on_side_streams(backend, parts):
-    """Knob lu_parts: the factorisation of a batch as 2 - 4 sub-batches on pooled side streams, each starting when the one before has finished
-    the panels of its first outer block (default from 16 matrices of at least 1024 rows on: two).  The arithmetic of a matrix does not depend
-    on which sub-batch it is in: factors, pivots and info are IDENTICAL to the one-batch run, bit for bit (uneven split: 5 matrices)."""
-    be = get_backend(backend)
-    n, batch = (300, 5) if backend == "emu" else (700, 5)
-    rng = np.random.default_rng(77)
-    A = (rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))).astype(np.complex128)
-    A[3, :, 5] = 0.0                # a singular member: its info must land in ITS slot
-    B = (rng.standard_normal((batch, n, 4)) + 1j * rng.standard_normal((batch, n, 4))).astype(np.complex128)
-    res = []
-    for p in (1, parts):
-        assert be.lib.tuning(b"lu_parts", p) == 0
-        try:
-            dA, dB = be.dev(A), be.dev(B)
-            piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
-            assert be.lib.lu_solve(dtcode(np.complex128), be.ptr(dA), n, be.ptr(dB), 4, batch, be.ptr(piv), be.ptr(info), be.stream) == 0
-        finally:
-            be.lib.tuning(b"lu_parts", 0)
-        res.append((be.host(dA), be.host(piv), be.host(info)))
-    assert (res[0][2] == res[1][2]).all() and res[0][2][3] != 0 and (np.delete(res[0][2], 3) == 0).all()
-    assert (res[0][1] == res[1][1]).all()
-    ok = [b for b in range(batch) if b != 3]
-    assert np.array_equal(res[0][0][ok], res[1][0][ok])
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
 def test_lu_row_split_singular_info(backend):
     be = get_backend(backend)
     n = 300

@@ -89,9 +89,12 @@ def test_config5_fom_and_gradient(order, fixture):
         fom.sum().backward()
     finally:
         torcwa_amd.Eig.broadening_parameter = old
+    # relative to the largest of the four: the cross-polarised pairs vanish by the mirror symmetry of the density (1e-12 at [25,25]) and are
+    # rounding noise of size eps * cond in BOTH implementations (the same rule as check_against_golden)
+    scale = max(max(abs(complex(np.asarray(g[f"t1{p}"]).reshape(-1)[0])) for p in ts), 1e-3)
     for p, t in ts.items():
         ref = complex(np.asarray(g[f"t1{p}"]).reshape(-1)[0])
-        assert abs(complex(t.detach().reshape(-1)[0]) - ref) / max(abs(ref), 1e-3) < 1e-9, p
+        assert abs(complex(t.detach().reshape(-1)[0]) - ref) / scale < 1e-9, p
     fref = float(np.asarray(g["fom"]).reshape(-1)[0])
     assert abs(float(fom.detach().reshape(-1)[0]) - fref) / fref < 1e-9
     gr = rho.grad.cpu().numpy()

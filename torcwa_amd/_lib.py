@@ -41,9 +41,6 @@ _SIGS = {
     "trx_build_a_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "trx_build_a": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "trx_tuning": (c_int, [c_char_p, c_int]),
-    "trx_stream_create_cumask": (c_int, [c_void_p, c_void_p, c_int]),
-    "trx_stream_destroy": (c_int, [c_void_p]),
-    "trx_lanes_cumask": (c_int, [c_void_p, c_int]),
     "trx_prof_enable": (c_int, [c_int]),
     "trx_prof_reset": (c_int, []),
     "trx_prof_get": (c_int, [c_int, c_void_p]),

@@ -82,22 +82,3 @@ extern "C" int trx_inverse(int dtype, void* A, int n, int batch, int* piv, int* 
     return TRX_ERR_DTYPE;
 }
 
-// ---- CU-partitioned streams (additive; see include/trx.h) ----------------------------------------------------------------------------
-extern "C" int trx_stream_create_cumask(void** stream, const unsigned* mask, int words) {
-    if (!stream || !mask || words <= 0 || words > 64) return TRX_ERR_ARG;
-    (void)hipGetLastError();
-    hipStream_t s = nullptr;
-    if (hipExtStreamCreateWithCUMask(&s, (unsigned)words, mask) != hipSuccess) { (void)hipGetLastError(); return TRX_ERR_LAUNCH; }
-    *stream = (void*)s;
-    return TRX_OK;
-}
-
-extern "C" int trx_stream_destroy(void* stream) {
-    if (!stream) return TRX_ERR_ARG;
-    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? TRX_OK : TRX_ERR_LAUNCH;
-}
-
-extern "C" int trx_lanes_cumask(const unsigned* mask, int words) {
-    if (words < 0 || words > 64 || (words > 0 && !mask)) return TRX_ERR_ARG;
-    return trx::lanes_set_cumask(mask, words);
-}

@@ -216,12 +216,6 @@ void gemm_big_tile(int* bm, int* bn);
 int gemm_big(hipStream_t s, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,
              int ldb, long sB, cx<double> beta, cx<double>* C, int ldc, long sC, int batch, int b_upper);
 int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_big", 0 / 4)
-int lanes_set_cumask(const unsigned* mask, int words);  // eig_qr.hip: CU mask of the pooled internal streams
-// a non-blocking stream + timing-less events from the process-wide pool of eig_qr.hip, checked out for the duration of one call
-// (sub-batches of the Hessenberg reduction and of the LU factorisation run on these)
-struct SideStream { hipStream_t s = nullptr; hipEvent_t ev = nullptr, ev2 = nullptr, ev3 = nullptr; int* hsum = nullptr; int dev = -1; };
-bool side_stream_checkout(SideStream& out);
-void side_stream_return(const SideStream& in);
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);

@@ -379,7 +379,6 @@ extern "C" int trx_tuning(const char* key, int value) {
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::refine_set_knob(key, value);
-    if (rc != TRX_OK) rc = trx::hess_set_knob(key, value);
     return rc;
 }
 

@@ -104,7 +104,6 @@ template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, 
 // Schur form: T in A, unitary accumulated into Z
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
 int qr_set_knob(const char* key, int value);
-int hess_set_knob(const char* key, int value);
 int eig_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 // V <- D V (undo of the balancing) with unit 2-norm columns

@@ -281,27 +281,11 @@ static int hess_rpw(int batch) {
     return v ? v : (batch >= 64 ? 2 : 4);
 }
 
-// Sub-batches of the reduction on their own streams (trx_tuning("hess_split", k) / TRX_HESS_SPLIT; 0 / 1 = off: the default, see hessenberg()).  A panel is a
-// column loop bound by the HBM stream (gemv) and by one-workgroup latency (reflector), followed by GEMM-shaped block updates bound by the
-// matrix cores; run as ONE lock-step batch the two never overlap and HBM idles during every reflector kernel (10 % of the loop).  Two
-// sub-batches half a panel out of phase put one's block updates and reflector kernels under the other's stream.
-static int hess_split_env() {
-    const char* e = getenv("TRX_HESS_SPLIT");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 0 && v <= 4) ? v : 0;
-}
-static int g_hess_split = hess_split_env();
-int hess_set_knob(const char* key, int value) {
-    if (std::string(key) != "hess_split" || value < 0 || value > 4) return TRX_ERR_ARG;
-    g_hess_split = value;
-    return TRX_OK;
-}
-
-// One (sub-)batch on stream s.  wait_ev: the stream waits for it before the first launch (null: none); mark_ev: recorded behind the column
-// loop of the first panel (null: none) -- the start signal of the next sub-batch.
+// (Two to four sub-batches on side streams, half a panel out of phase -- one's block updates and reflector kernels under the other's gemv
+// stream -- were measured in round 6 and removed: the phase takes 882 ms as one batch of 128 and 914 / 946 / 1001 ms as 2 / 3 / 4 sub-batches;
+// two chip-filling gemv grids share the chip instead of overlapping.  profiles/r06_ab/cumask.txt)
 template <class T>
-static int hessenberg_sub(hipStream_t s, const EigBuffers<T>& B, int n, int batch, hipEvent_t wait_ev, hipEvent_t mark_ev) {
-    if (wait_ev && hipStreamWaitEvent(s, wait_ev, 0) != hipSuccess) return TRX_ERR_LAUNCH;
+int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     const cx<T> one(T(1), T(0)), mone(T(-1), T(0)), zero(T(0), T(0));
     const long nn = (long)n * n, sV = (long)n * HNB, sT = HNB * HNB, sW = (long)HNB * n;
     cx<T>*A = B.A, *Z = B.Z, *V = B.Vp, *Y = B.Yp, *Tm = B.Tp, *W = B.W1, *W2 = B.W2;
@@ -339,7 +323,6 @@ static int hessenberg_sub(hipStream_t s, const EigBuffers<T>& B, int n, int batc
                 TRX_LAUNCH((hess_gemv_kernel<T, 2>), dim3(nwg, batch), dim3(gthreads), smg, s, (const cx<T>*)A, n, r0, j, c, next, (const cx<T>*)V, Y,
                            (const cx<T>*)B.tau, (const cx<T>*)B.tvec, Bcol, wpart, rpb);
         }
-        if (p0 == 0 && mark_ev && hipEventRecord(mark_ev, s) != hipSuccess) return TRX_ERR_LAUNCH;
         int rc;
         const int mt = n - p0 - ib;       // trailing columns
         // (1) Ytop = (A[0:r0, r0:n] V[r0:n,:]) T
@@ -379,56 +362,6 @@ static int hessenberg_sub(hipStream_t s, const EigBuffers<T>& B, int n, int batc
     }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
-}
-
-template <class T>
-int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
-    // Off unless asked for.  Measured on MI355X (profiles/r06_ab/r6a_first_call.txt, n = 1922): the Hessenberg phase of the 128-matrix
-    // step takes 882 ms as one batch and 914 / 946 / 1001 ms as 2 / 3 / 4 sub-batches (batch 16: 181 vs 217 ms) -- two chip-filling gemv
-    // grids do not overlap, they share the chip, and the reflector kernel of one queues behind the workgroups of the other.
-    int parts = g_hess_split > 1 ? g_hess_split : 1;
-    if (parts > batch) parts = batch;
-    if (parts <= 1) return hessenberg_sub<T>(s, B, n, batch, nullptr, nullptr);
-    SideStream side[4];
-    int nside = 0, rc = TRX_OK;
-    for (int k = 1; k < parts; ++k) {
-        if (!side_stream_checkout(side[k])) { rc = TRX_ERR_LAUNCH; break; }
-        ++nside;
-    }
-    SideStream fork;
-    bool have_fork = false;
-    if (!rc) { have_fork = side_stream_checkout(fork); if (!have_fork) rc = TRX_ERR_LAUNCH; }
-    if (!rc && hipEventRecord(fork.ev, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
-    int b0 = 0;
-    for (int k = 0; k < parts && !rc; ++k) {
-        const int nb = (batch - b0) / (parts - k);
-        EigBuffers<T> S = B;
-        const long nn = (long)n * n;
-        S.A = B.A + b0 * nn; S.Z = B.Z + b0 * nn;
-        S.Vp = B.Vp + (long)b0 * n * HNB; S.Yp = B.Yp + (long)b0 * n * HNB; S.Tp = B.Tp + (long)b0 * HNB * HNB;
-        S.W1 = B.W1 + (long)b0 * HNB * n; S.W2 = B.W2 + (long)b0 * HNB * n;
-        S.YV = B.YV + (long)b0 * n * 2 * HNB; S.BC = B.BC + (long)b0 * 2 * HNB * n; S.Sm = B.Sm + (long)b0 * HNB * HNB;
-        S.tau = B.tau + (long)b0 * HNB; S.tvec = B.tvec + (long)b0 * HNB;
-        hipStream_t sk = k == 0 ? s : side[k].s;
-        if (k > 0 && hipStreamWaitEvent(sk, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-        // sub-batch k starts when sub-batch k-1 has left the column loop of its first panel; the mark of sub-batch k is side[k + 1]'s event
-        rc = hessenberg_sub<T>(sk, S, n, nb, k > 0 ? side[k].ev : nullptr, k + 1 < parts ? side[k + 1].ev : nullptr);
-        b0 += nb;
-    }
-    // join: the caller's stream waits for every side stream (events of the side lanes are free again: their marks were consumed above)
-    for (int k = 1; k <= nside; ++k) {
-        if (!rc && (hipEventRecord(side[k].ev2, side[k].s) != hipSuccess || hipStreamWaitEvent(s, side[k].ev2, 0) != hipSuccess)) rc = TRX_ERR_LAUNCH;
-        if (rc) (void)hipStreamSynchronize(side[k].s);       // error path: nothing of this call may still be queued when the lane goes back
-    }
-    // a lane may only go back to the pool when its work is ordered before whatever the next user queues: the join event does that for
-    // the caller's stream; another caller could check the lane out at once, so wait for its queue to drain first (it is short by then:
-    // the host ran ahead of the device by at most the launches of this call)
-    for (int k = 1; k <= nside; ++k) {
-        if (hipStreamSynchronize(side[k].s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
-        side_stream_return(side[k]);
-    }
-    if (have_fork) side_stream_return(fork);
-    return rc;
 }
 
 template int hessenberg<float>(hipStream_t, const EigBuffers<float>&, int, int);

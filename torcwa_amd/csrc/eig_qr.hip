@@ -1271,7 +1271,7 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256, APPLY_MIN_WG(T)) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                           const QrLink* __restrict__ links_all, const cx<T>* __restrict__ Ulog_all,
                                                           const cx<T>* __restrict__ Udense_all, unsigned* __restrict__ work, int nslot, int kc,
-                                                          int q0, int nq, int spw, int units, int band_on) {
+                                                          int q0, int nq, int spw, int units, int band_on, int g_lo, int g_hi) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1305,13 +1305,14 @@ __global__ __launch_bounds__(256, APPLY_MIN_WG(T)) void apply_links_kernel(cx<T>
                 nL = n > e ? (n - e + 15) >> 4 : 0;
                 if (MODE == 2) { nR = (w0 + 15) >> 4; nZ = (n + 15) >> 4; }
                 S = nL + nR + nZ;
-                g0 = gx * (4 * spw);
+                if (MODE == 0) { S = S < g_hi ? S : g_hi; }        // strips [g_lo, g_hi) of the link only (near / far part of the left update)
+                g0 = (MODE == 0 ? g_lo : 0) + gx * (4 * spw);
                 if (g0 >= S) continue;
             } else {
                 if (row0 >= (isZ ? n : w0)) continue;
             }
             if (gx == 0 && t == 0)      // algorithmic work of this link's update, in units of 4096 complex MACs
-                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (MODE == 2 ? 2L * n - ww : (long)(n > e ? n - e : 0)))) >> 12));
+                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (MODE == 2 ? 2L * n - ww : (long)(16 * (S - g_lo) < n - e - 16 * g_lo ? 16 * (S - g_lo) : n - e - 16 * g_lo)))) >> 12));
             const cx<T>* U = MODE == 2 ? Udense_all + (long)b * QW * QW : Ulog_all + (((long)b * nslot + qq) * kc + ch) * QW * QW;
             // Per link: (1) ALL global loads up front -- the 16 U elements of this thread and the first strip's 64 x 16 block (both only depend on
             // what this wave itself stored for the previous link) -- (2) barrier: the previous link's readers are done with the planes, (3) U
@@ -1403,7 +1404,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0, far = 0, near = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1426,6 +1427,7 @@ static QrKnobs& qr_knobs() {
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
         q.defer = geti("TRX_QR_DEFER", 0, 2, 0);              // right / Z update: 0 automatic, 1 behind every (super-)step, 2 once per sweep
+        q.far = geti("TRX_QR_FAR", 0, 2, 0);                  // left update beyond the next launch's columns on a second stream per group: 0 automatic (on), 1 off, 2 on
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1448,14 +1450,6 @@ struct QrLane {
 };
 static std::mutex g_lane_mu;
 static std::vector<QrLane> g_lane_free;
-// CU mask of the pooled streams (trx_lanes_cumask): empty = unrestricted.  Lanes are created on first use and kept, so the mask applies to
-// the lanes created after it was set (set it before the first trx_eig of the process).
-static std::vector<unsigned> g_lane_mask;
-int lanes_set_cumask(const unsigned* mask, int words) {
-    std::lock_guard<std::mutex> lock(g_lane_mu);
-    g_lane_mask.assign(mask, mask + (words > 0 ? words : 0));
-    return TRX_OK;
-}
 static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
     {
         std::lock_guard<std::mutex> lock(g_lane_mu);
@@ -1465,12 +1459,7 @@ static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
     out = QrLane();
     out.dev = dev;
     out.has_stream = want_stream;
-    if (want_stream) {
-        std::vector<unsigned> mask;
-        { std::lock_guard<std::mutex> lock(g_lane_mu); mask = g_lane_mask; }
-        if (mask.empty() ? hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess
-                         : hipExtStreamCreateWithCUMask(&out.s, (unsigned)mask.size(), mask.data()) != hipSuccess) return false;
-    }
+    if (want_stream && hipStreamCreateWithFlags(&out.s, hipStreamNonBlocking) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&out.ev, hipEventDisableTiming) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&out.evs[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&out.evs[1], hipEventDisableTiming) != hipSuccess) return false;
     if (hipHostMalloc((void**)&out.hsum, sizeof(int) * 8, hipHostMallocDefault) != hipSuccess) return false;
@@ -1479,21 +1468,6 @@ static bool lane_checkout(int dev, bool want_stream, QrLane& out) {
 static void lane_return(const QrLane& l) {
     std::lock_guard<std::mutex> lock(g_lane_mu);
     g_lane_free.push_back(l);
-}
-
-// A pooled side stream + event for the other stages of trx_eig (sub-batches of the Hessenberg reduction): same pool, same rules.
-bool side_stream_checkout(SideStream& out) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    QrLane l;
-    if (!lane_checkout(dev, true, l)) return false;
-    out.s = l.s; out.ev = l.ev; out.ev2 = l.evs[0]; out.ev3 = l.evs[1]; out.hsum = l.hsum; out.dev = l.dev;
-    return true;
-}
-void side_stream_return(const SideStream& in) {
-    QrLane l;
-    l.s = in.s; l.ev = in.ev; l.evs[0] = in.ev2; l.evs[1] = in.ev3; l.hsum = in.hsum; l.dev = in.dev; l.has_stream = true;
-    lane_return(l);
 }
 
 // trx_tuning(): the environment variables only provide the defaults (read once); this sets a knob explicitly.  0 = automatic.
@@ -1512,6 +1486,8 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
     else if (s == "qr_defer") { slot = &k.defer; hi = 2; }
+    else if (s == "qr_far") { slot = &k.far; hi = 2; }
+    else if (s == "qr_near") { slot = &k.near; hi = 4096; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1564,6 +1540,17 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // window steps per launch: super-steps need one chain per sweep (several chains advance in lock-step, one window step per launch)
     const int super = kc == 1 ? (K.super ? K.super : (sizeof(T) == 4 ? 4 : 8)) : 1;          // measured: fp32 4 (2 / 8 within 0.5 %), fp64 8 (28.4 vs 28.1 layer-solves/s on the all-fp64 route)
     const bool defer = kc == 1 && K.defer != 1;
+    // The left update of a super-step in two parts.  What the NEXT launch of the chain needs of it are only the columns its windows and its
+    // in-kernel band reach: the first `gnear` 16-column strips right of this launch's band (a launch advances by at most super * 61 columns).
+    // Those stay on the group's stream (near part: a quarter of a millisecond of chain per iteration instead of two); the rest -- up to 1900
+    // columns, 76 us of chip-filling matrix-core work alone and 207 us in situ, eleven times per iteration on the critical path of rounds
+    // 4 - 5 -- goes to a SECOND stream of the group and runs under the next chase launch (far part).  Orders kept by events: far(S) after
+    // chase(S) (unitaries, band), near(S + 1) after far(S) (same strips, links in order), the sweep's deferred right / Z update and everything
+    // after it behind the last far part.
+    const bool far_on = defer && K.far != 1 && batch >= 2;
+    // (knob qr_near: strips of the near part, for tests of the far path on matrices too small to have one -- only safe where launches run in
+    // issue order, i.e. on the CPU kernel-logic emulator)
+    const int gnear = K.near ? K.near : cdiv_i(super * (QW - 1), 16) + 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1573,6 +1560,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     constexpr int MAXG = 8;
     struct Group {
         QrLane lane;           // streams + events
+        QrLane far;            // second stream of the group: the part of the left update the next launch does not wait for (see issue_sweep)
+        bool has_far, far_pending;
         hipStream_t s;
         int b0, nb;
         int* summary;          // device, 16 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
@@ -1587,10 +1576,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
     if (ngroups > batch) ngroups = batch;
     Group grp[MAXG];
+    for (int g = 0; g < MAXG; ++g) { grp[g].has_far = false; grp[g].far_pending = false; }
     int rc = TRX_OK, dev = 0, nlanes = 0;
     (void)hipGetDevice(&dev);
     QrLane fork;
-    if (ngroups > 1) {
+    const bool need_fork = ngroups > 1 || far_on;
+    if (need_fork) {
         if (!lane_checkout(dev, false, fork) || hipEventRecord(fork.ev, s) != hipSuccess) return TRX_ERR_LAUNCH;
     }
     for (int g = 0; g < ngroups; ++g) {
@@ -1607,8 +1598,14 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.work[0] = G.work[1] = G.work[2] = G.work[3] = 0;
         G.par = 0;
         G.g = g;
+        G.has_far = false; G.far_pending = false;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
         ++nlanes;
+        if (far_on) {
+            if (!lane_checkout(dev, true, G.far)) { rc = TRX_ERR_LAUNCH; break; }
+            G.has_far = true;
+            if (hipStreamWaitEvent(G.far.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }      // (everything the caller queued before this call)
+        }
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
@@ -1667,23 +1664,43 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
               if (q == 0) {      // the dense link of slot 0, if there is one: left | right-H | Z, up to 3 n / 16 + 3 strips
                   const int du = cdiv_i(3 * nstrip + 3, 4 * spw);
-                  TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on);
+                  TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on, 0, 1 << 30);
               }
               const int units = cdiv_i(nstrip + 1, 4 * spw);
-              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
+              if (G.has_far && q > 0) {
+                  // near part on the group's stream (after the far part of the launch before: same strips, links in order) ...
+                  const int un = cdiv_i(gnear, 4 * spw);
+                  if (hipEventRecord(G.far.evs[0], G.s) != hipSuccess) return false;                            // "chase(S) done"
+                  if (G.far_pending && hipStreamWaitEvent(G.s, G.far.ev, 0) != hipSuccess) return false;        // far(S - 1) done
+                  TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * un, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, un, band_on, 0, gnear);
+                  // ... far part on the second stream, under the next chase launch
+                  if (hipStreamWaitEvent(G.far.s, G.far.evs[0], 0) != hipSuccess) return false;
+                  { ProfScope pf(PROF_QR_APPLY_LEFT, G.far.s, 0, 0);
+                    TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.far.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on, gnear, 1 << 30); }
+                  if (hipEventRecord(G.far.ev, G.far.s) != hipSuccess) return false;
+                  G.far_pending = true;
+              } else {
+                  TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on, 0, 1 << 30);
+              }
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
               // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
               // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
               if (!defer)
-                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
+                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on, 0, 1 << 30); }
             q += ns;
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
         // deflation), so it cannot run beside it.
+        if (G.far_pending) {
+            // join: the far parts touch rows of this sweep's windows in the columns right of them -- the rows x columns the deferred right
+            // update below (and the next prepare, and the next sweep) work on
+            if (hipStreamWaitEvent(G.s, G.far.ev, 0) != hipSuccess) return false;
+            G.far_pending = false;
+        }
         if (defer) {
             ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on);
+            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on, 0, 1 << 30);
         }
         return true;
     };
@@ -1757,7 +1774,13 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         }
         lane_return(G.lane);
     }
-    if (ngroups > 1) lane_return(fork);
+    for (int g = 0; g < ngroups; ++g)
+        if (grp[g].has_far) {
+            // every far part has been joined into its group's stream above; the lane goes back to the pool with an empty queue
+            if (hipStreamSynchronize(grp[g].far.s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
+            lane_return(grp[g].far);
+        }
+    if (need_fork) lane_return(fork);
     if (rc) return rc;
     if (qr_debug) {
         long long h[24];

@@ -447,7 +447,6 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
-int lu_parts_knob(int value);
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
@@ -456,7 +455,6 @@ int lu_set_knob(const char* key, int value) {
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
     if (k == "lu_split") g_lu_split_rows = value;
     else if (k == "lu_split_batch") g_lu_split_batch = value;
-    else if (k == "lu_parts") return lu_parts_knob(value);
     else return TRX_ERR_ARG;
     return TRX_OK;
 }
@@ -539,18 +537,17 @@ int lu_block_update(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
     return TRX_OK;
 }
 
-// One (sub-)batch on stream s.  wait_ev: the stream waits for it before the first launch; mark_ev: recorded behind the panels of the first
-// outer block (the start signal of the next sub-batch, see lu_factor).
+// (Two sub-batches on side streams -- one's panel chains under the other's trailing update -- were measured in round 6: 33.61 against 33.43
+// layer-solves/s at batch 128, 15.76 against 15.98 at batch 16: noise, removed; profiles/r06_ab/cumask.txt.)
 template <class T>
-static int lu_factor_sub(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info, hipEvent_t wait_ev, hipEvent_t mark_ev) {
-    if (wait_ev && hipStreamWaitEvent(s, wait_ev, 0) != hipSuccess) return TRX_ERR_LAUNCH;
+int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
+    if (n <= 0 || batch <= 0) return TRX_OK;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
     for (int K0 = 0; K0 < n; K0 += NBO) {
         const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
         const int Kend = K0 + kb;
         int rc = lu_block_panels<T>(s, A, lda, sA, n, K0, Kend, piv, batch, info);
         if (rc) return rc;
-        if (K0 == 0 && mark_ev && hipEventRecord(mark_ev, s) != hipSuccess) return TRX_ERR_LAUNCH;
         // the block's interchanges on the columns left and right of it
         const int outside = K0 + (n - Kend);
         if (outside > 0)
@@ -560,54 +557,6 @@ static int lu_factor_sub(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* 
     }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
-}
-
-// Sub-batches on pooled side streams (trx_tuning("lu_parts", k) / TRX_LU_PARTS; 0 = automatic, 1 = off): an outer block is a chain of panel
-// kernels -- per-column launches bound by latency, a few workgroups per matrix -- followed by a rank-256 trailing update bound by the matrix
-// cores.  As ONE lock-step batch the two alternate and the matrix cores idle through every panel chain; two sub-batches, the second started
-// when the first has finished the panels of its first outer block, put one's panel chains under the other's trailing update.  (Not the
-// look-ahead of round 4, which overlapped the panels and the update of the SAME matrices and had to split that update.)
-static int lu_parts_env() { const char* e = getenv("TRX_LU_PARTS"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }
-static int g_lu_parts = lu_parts_env();
-int lu_parts_knob(int value) {
-    if (value < 0 || value > 4) return TRX_ERR_ARG;
-    g_lu_parts = value;
-    return TRX_OK;
-}
-
-template <class T>
-int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info) {
-    if (n <= 0 || batch <= 0) return TRX_OK;
-    int parts = g_lu_parts ? g_lu_parts : ((batch >= 16 && n >= 1024) ? 2 : 1);
-    if (parts > batch) parts = batch;
-    if (parts <= 1) return lu_factor_sub<T>(s, A, lda, sA, n, piv, batch, info, nullptr, nullptr);
-    SideStream side[4], fork;
-    int nside = 0, rc = TRX_OK;
-    for (int k = 1; k < parts; ++k) {
-        if (!side_stream_checkout(side[k])) { rc = TRX_ERR_LAUNCH; break; }
-        ++nside;
-    }
-    bool have_fork = false;
-    if (!rc) { have_fork = side_stream_checkout(fork); if (!have_fork) rc = TRX_ERR_LAUNCH; }
-    if (!rc && hipEventRecord(fork.ev, s) != hipSuccess) rc = TRX_ERR_LAUNCH;
-    int b0 = 0;
-    for (int k = 0; k < parts && !rc; ++k) {
-        const int nb = (batch - b0) / (parts - k);
-        hipStream_t sk = k == 0 ? s : side[k].s;
-        if (k > 0 && hipStreamWaitEvent(sk, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
-        rc = lu_factor_sub<T>(sk, A + (long)b0 * sA, lda, sA, n, piv + (long)b0 * n, nb, info + b0, k > 0 ? side[k].ev : nullptr, k + 1 < parts ? side[k + 1].ev : nullptr);
-        b0 += nb;
-    }
-    for (int k = 1; k <= nside; ++k) {
-        if (!rc && (hipEventRecord(side[k].ev2, side[k].s) != hipSuccess || hipStreamWaitEvent(s, side[k].ev2, 0) != hipSuccess)) rc = TRX_ERR_LAUNCH;
-    }
-    // a lane goes back to the pool only when its queue has drained (another caller may check it out at once)
-    for (int k = 1; k <= nside; ++k) {
-        if (hipStreamSynchronize(side[k].s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
-        side_stream_return(side[k]);
-    }
-    if (have_fork) side_stream_return(fork);
-    return rc;
 }
 
 template <class T>

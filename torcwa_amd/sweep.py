@@ -131,50 +131,9 @@ def _slice(v, lo, hi, B):
     return v
 
 
-# ---- CU-partitioned streams (include/trx.h: trx_stream_create_cumask) -----------------------------------------------------------------------
-_MASKED = {}          # (device index, reserve, order) -> [torch.cuda.ExternalStream, ...]: created once, kept for the life of the process
-
-
-def cu_masks(n_cu, reserve, order="interleaved"):
-    """(throughput mask, reserved mask) as lists of 32-bit words over `n_cu` compute units: `reserve` CUs, spread evenly over the 8 XCDs, are
-    taken out of the throughput mask.  order = bit order of the driver's CU mask: "interleaved" (bit i = CU i // 8 of XCD i % 8: the
-    reserved CUs are bits [0, reserve)) or "xcdmajor" (bit i = CU i % 32 of XCD i // 32: bits 32 x + j, j < reserve / 8)."""
-    words = (n_cu + 31) // 32
-    res = [0] * words
-    per_xcd = max(1, reserve // 8)
-    for i in range(n_cu):
-        hit = (i < reserve) if order == "interleaved" else ((i % 32) < per_xcd)
-        if hit:
-            res[i // 32] |= 1 << (i % 32)
-    full = [(0xFFFFFFFF if 32 * (w + 1) <= n_cu else (1 << (n_cu - 32 * w)) - 1) for w in range(words)]
-    return [f & ~r & 0xFFFFFFFF for f, r in zip(full, res)], res
-
-
-def masked_streams(engine, dev, count, reserve, order="interleaved", lanes="free"):
-    """`count` HIP streams for the chunks of a sweep that leave `reserve` CUs to the latency-bound kernels of trx_eig (its pooled internal
-    streams: lanes = "free" -> unrestricted, they find the reserved CUs empty; "reserved" -> restricted to the reserved CUs)."""
-    import ctypes
-    key = (dev.index, count, reserve, order, lanes)
-    if key not in _MASKED:
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        thr, res = cu_masks(n_cu, reserve, order)
-        arr = (ctypes.c_uint32 * len(thr))(*thr)
-        pool = []
-        for _ in range(count):
-            h = ctypes.c_void_p()
-            engine.lib.check(engine.lib.stream_create_cumask(ctypes.addressof(h), ctypes.addressof(arr), len(thr)))
-            pool.append(torch.cuda.ExternalStream(h.value, device=dev))
-        if lanes == "reserved":
-            rarr = (ctypes.c_uint32 * len(res))(*res)
-            engine.lib.check(engine.lib.lanes_cumask(ctypes.addressof(rarr), len(res)))
-        _MASKED[key] = pool
-    return _MASKED[key]
-
-
 def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_ang=0.0, azi_ang=0.0, dtype=torch.complex64,
                       precision="high", engine=None, chunk=None, streams=1, orders=((0, 0),), polarization="xx",
-                      direction="forward", port="transmission", check_info=True, eig_route="auto", cu_reserve=0, cu_order="interleaved",
-                      cu_lanes="free"):
+                      direction="forward", port="transmission", check_info=True, eig_route="auto"):
     """B sweep points of a multi-layer stack (BASELINE.json configs 2-4): the reference's per-point Python loop
     (example/Example1-1.ipynb, Example3.ipynb) as chunks of a batched solve.  `layers` as in `_solve_chunk`, with
     per-point quantities carrying a leading dimension B = len(freq).  Returns the requested S-parameter [B, len(orders)].
@@ -201,25 +160,21 @@ def solve_stack_sweep(freq, layers, order, L, *, eps_in=None, eps_out=None, inc_
                                eig_route=eig_route, route_hint=route_hint)
 
     dev = freq.device
-    pool = None
-    if streams > 1 and cu_reserve > 0 and dev.type == "cuda" and len(spans) > 1:
-        pool = masked_streams(eng, dev, streams, cu_reserve, cu_order, cu_lanes)
     try:
-        _run_spans(run, spans, streams, dev, pool)
+        _run_spans(run, spans, streams, dev)
     finally:
         eng.check_info = old_check
     return torch.cat(outs, dim=0)
 
 
-def _run_spans(run, spans, streams, dev, pool=None):
+def _run_spans(run, spans, streams, dev):
     import threading
     if streams <= 1 or len(spans) == 1 or dev.type != "cuda":
         for i in range(len(spans)):
             run(i)
     else:
         cur = torch.cuda.current_stream(dev)
-        if pool is None:
-            pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
         errors = []
 
         def worker(w):
@@ -248,8 +203,8 @@ def solve_single_layer_sweep(freq, eps_grids, thickness, order, L, **kw):
     chunk   : points solved in lock-step by one batched solver (bounds the HBM footprint; default None = as many as the free HBM holds with
               10 % headroom, `auto_chunk`).  At order [15,15] (n = 1922) a point costs about 0.6 GB allocated / 0.9 GB reserved, so about 256 points
               fit the 288 GB of an MI355X, and larger chunks are faster (measured, round 5: 15.7 / 22.1 / 27.9 / 32.2 layer-solves/s at 16 / 32 / 64 / 128 points).
-    streams : number of HIP streams / host threads the chunks are dealt to (default 1).  With cu_reserve = K > 0 the streams are created with a
-              CU mask that leaves K compute units (K / 8 per XCD) to the latency-bound kernels of the eigensolver, so that a chip-filling GEMM
-              of one chunk cannot starve the QR chains of the other (profiles/r06_ab/cumask.txt).
+    streams : number of HIP streams / host threads the chunks are dealt to (default 1: one lock-step chunk is faster on MI355X -- two half
+              sweeps on two threads 18.3 layer-solves/s against 33.6, and 28.9 - 31.3 with CU-masked streams that keep the other half's GEMM
+              grids off a reserved set of compute units: profiles/r06_ab/cumask.txt).
     """
     return solve_stack_sweep(freq.to(eps_grids.device), [(thickness, eps_grids)], order, L, **kw)
