@@ -290,15 +290,6 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 template <class T>
 inline T __builtin_amdgcn_readfirstlane(T v) { return __shfl(v, 0); }
 inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
-// DPP whole-wave shifts by one lane (the two controls libtrx uses): wave_shl:1 (0x130) -- lane i reads lane i + 1; wave_shr:1 (0x138) --
-// lane i reads lane i - 1; a lane without a source keeps `old` (bound_ctrl off).
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
-    ::hipemu::wave_post(src);
-    const int l = ::hipemu::lane_id();
-    const int sl = ctrl == 0x130 ? l + 1 : (ctrl == 0x138 ? l - 1 : -1);
-    if (ctrl != 0x130 && ctrl != 0x138) { fprintf(stderr, "hipemu: DPP control 0x%x not modelled\n", ctrl); abort(); }
-    return (sl < 0 || sl > 63) ? old : ::hipemu::wave_read<int>(sl);
-}
 
 // ---- MFMA (fragment maps per /opt/skills/guides/cdna_hip_programming.md section 3) --------------------
 typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));

@@ -143,30 +143,6 @@ template <class T> __device__ __forceinline__ T bcast_lane(T v, int l) {
     return r;
 }
 
-// Value of the NEXT lane (lane + 1; lane 63 reads zero) / of the PREVIOUS lane (lane - 1; lane 0 reads zero): one v_mov_b32_dpp per dword
-// with the whole-wave shift controls of the gfx9 family (wave_shl:1 -- a lane reads its upper neighbour, wave_shr:1 -- its lower one).
-// Register-to-register inside the SIMD: no LDS crossbar as with __shfl_up / __shfl_down (ds_bpermute).
-template <class T> __device__ __forceinline__ T lane_from_next(T v) {
-    static_assert(sizeof(T) % 4 == 0, "dword multiple");
-    int w[sizeof(T) / 4];
-    __builtin_memcpy(w, &v, sizeof(T));
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = __builtin_amdgcn_update_dpp(0, w[i], 0x130, 0xF, 0xF, false);
-    T r;
-    __builtin_memcpy(&r, w, sizeof(T));
-    return r;
-}
-template <class T> __device__ __forceinline__ T lane_from_prev(T v) {
-    static_assert(sizeof(T) % 4 == 0, "dword multiple");
-    int w[sizeof(T) / 4];
-    __builtin_memcpy(w, &v, sizeof(T));
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = __builtin_amdgcn_update_dpp(0, w[i], 0x138, 0xF, 0xF, false);
-    T r;
-    __builtin_memcpy(&r, w, sizeof(T));
-    return r;
-}
-
 // Ordering point inside a wave: lanes of one wavefront execute in lock-step, so this emits no instruction on gfx950; it
 // stops the compiler from moving LDS accesses across it (and is a rendezvous in the CPU kernel-logic emulator).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }

@@ -11,10 +11,13 @@
 //   1. bal_rownorm / bal_colnorm / bal_precheck (wide, batched): the norms of every index at once and zgebal's own acceptance
 //      test; a matrix in which no index asks for a scaling is already balanced (exactly what zgebal's first sweep would find)
 //      and skips everything else -- the normal case for RCWA operators: two streaming reads and no further cost.
-//   2. bal_seq_kernel (one 1024-thread workgroup per matrix that needs it): zgebal's sweeps over d until a sweep changes nothing,
-//      at most 4 of them (about 3.8 ms each at n = 1922: left to run to zgebal's own stopping rule the kernel took 41 ms per
-//      call on the RCWA operators of the bench, i.e. ~11 sweeps of late single-index corrections; every intermediate d is a
-//      valid similarity, and the first sweeps do the bulk of the equalisation).
+//   2. bal_sq_kernel + bal_seq_kernel (one 1024-thread workgroup per matrix that needs it): zgebal's sweeps over d until a sweep changes
+//      nothing, at most 4 of them, with the row / column sums maintained INCREMENTALLY: R_i = sum_j |a_ij|^2 d_j^2 and C_i = sum_j |a_ji|^2 /
+//      d_j^2 live in LDS (r_i^2 = R_i / d_i^2, c_i^2 = C_i d_i^2), an index that is left alone costs one scalar test, and an index that is
+//      scaled (d_k^2: w -> w') costs one coalesced pass over column k and row k of |A|^2 (R_i += |a_ik|^2 (w' - w), C_i += |a_ki|^2 (1/w' -
+//      1/w)) -- read from a float copy of |A|^2 and of its transpose (bal_sq_kernel, in the eigensolver's still unused Z buffer).  Same
+//      visiting order and acceptance test as before; rounds 2 - 5 recomputed both sums from the matrix for EVERY index (a strided column
+//      read each: 41 ms per call at the bench shape, one workgroup per matrix -- 4 % of a 16-point step).
 //   3. bal_apply_kernel: the one fused D^-1 A D pass.
 // The host never waits; per-matrix flags live on the device.
 #include "eig.hpp"
@@ -81,39 +84,67 @@ __global__ __launch_bounds__(256) void bal_precheck_kernel(const T* __restrict__
     if (bal_factor<T>(sqrt(c2all[(long)b * n + i]), sqrt(r2all[(long)b * n + i]), T(1)) != T(1)) need[b] = 1;
 }
 
-// zgebal's sequential sweeps on the scaling vector (held squared in LDS) against the unmodified matrix
-constexpr int BST = 1024;
+// M2[i][j] = |a_ij|^2 and M2T[j][i] = |a_ij|^2 as float (32 x 32 tiles through LDS: both written row-wise)
 template <class T>
-__global__ __launch_bounds__(BST) void bal_seq_kernel(const cx<T>* __restrict__ Aall, int n, T* __restrict__ dall, const int* __restrict__ need, int max_sweeps) {
-    TRX_DYN_SMEM(smem);
-    T* d2 = reinterpret_cast<T*>(smem);          // [n]   d_j^2
-    T* red = d2 + n;                             // [2 * BST/64] wave partials
-    __shared__ int changed;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+__global__ __launch_bounds__(256) void bal_sq_kernel(const cx<T>* __restrict__ Aall, int n, float* __restrict__ M2all, float* __restrict__ M2Tall, const int* __restrict__ need) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
     if (!need[b]) return;
     const cx<T>* A = Aall + (long)b * n * n;
-    for (int j = t; j < n; j += BST) d2[j] = T(1);
+    float* M2 = M2all + (long)b * n * n;
+    float* M2T = M2Tall + (long)b * n * n;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < n && c < n) { v = (float)norm2(A[(long)r * n + c]); M2[(long)r * n + c] = v; }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int r = c0 + i, c = r0 + tx;
+        if (r < n && c < n) M2T[(long)r * n + c] = tile[tx][i];
+    }
+}
+
+// zgebal's sequential sweeps on the scaling vector with incrementally maintained row / column sums (see the header)
+constexpr int BST = 1024;
+template <class T>
+__global__ __launch_bounds__(BST) void bal_seq_kernel(const float* __restrict__ M2all, const float* __restrict__ M2Tall, int n, const T* __restrict__ r2all,
+                                                      const T* __restrict__ c2all, T* __restrict__ dall, const int* __restrict__ need, int max_sweeps) {
+    TRX_DYN_SMEM(smem);
+    T* d2 = reinterpret_cast<T*>(smem);          // [n]   d_j^2
+    T* Rs = d2 + n;                              // [n]   sum_j |a_ij|^2 d_j^2
+    T* Cs = Rs + n;                              // [n]   sum_j |a_ji|^2 / d_j^2
+    __shared__ int changed;
+    __shared__ T upd[2];                         // (w' - w, 1/w' - 1/w) of the index being scaled; upd[0] == 0: left alone
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (!need[b]) return;
+    const float* M2 = M2all + (long)b * n * n;
+    const float* M2T = M2Tall + (long)b * n * n;
+    for (int j = t; j < n; j += BST) { d2[j] = T(1); Rs[j] = r2all[(long)b * n + j]; Cs[j] = c2all[(long)b * n + j]; }
     __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (t == 0) changed = 0;
         __syncthreads();
         for (int i = 0; i < n; ++i) {
-            T rs = T(0), cs = T(0);
-            for (int j = t; j < n; j += BST) {
-                const T w = d2[j];
-                rs += norm2(A[(long)i * n + j]) * w;             // sum_j |a_ij|^2 d_j^2
-                cs += norm2(A[(long)j * n + i]) / w;             // sum_j |a_ji|^2 / d_j^2
-            }
-            rs = wave_sum(rs);
-            cs = wave_sum(cs);
-            if (lane == 0) { red[2 * wv] = rs; red[2 * wv + 1] = cs; }
-            __syncthreads();
             if (t == 0) {
-                T r2 = T(0), c2 = T(0);
-                for (int q = 0; q < BST / 64; ++q) { r2 += red[2 * q]; c2 += red[2 * q + 1]; }
-                const T di2 = d2[i];
-                const T f = bal_factor<T>(sqrt(c2 * di2), sqrt(r2 / di2), sqrt(di2));
-                if (f != T(1)) { d2[i] = di2 * f * f; changed = 1; }
+                const T w = d2[i];
+                const T f = bal_factor<T>(sqrt(Cs[i] * w), sqrt(Rs[i] / w), sqrt(w));
+                if (f != T(1)) {
+                    const T w2 = w * f * f;
+                    upd[0] = w2 - w; upd[1] = T(1) / w2 - T(1) / w;
+                    d2[i] = w2; changed = 1;
+                } else upd[0] = T(0);
+            }
+            __syncthreads();
+            const T dw = upd[0];
+            if (dw != T(0)) {                    // (workgroup-uniform)
+                const T diw = upd[1];
+                for (int k = t; k < n; k += BST) {
+                    Rs[k] += (T)M2T[(long)i * n + k] * dw;          // |a_ki|^2: column i of |A|^2 = row i of its transpose
+                    Cs[k] += (T)M2[(long)i * n + k] * diw;          // |a_ik|^2: row i
+                }
             }
             __syncthreads();
         }
@@ -146,13 +177,17 @@ int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     T* r2 = B.bal_w;                       // [2][B,n]: r2, c2
     T* c2 = r2 + (long)batch * n;
     int* need = B.bal_flags;               // [B] matrix needs balancing
-    const size_t smq = sizeof(T) * ((size_t)n + 2 * (BST / 64));
+    const size_t smq = sizeof(T) * 3 * (size_t)n;
+    // |A|^2 and its transpose as float: 8 n^2 bytes per matrix, in Z (16 / 8 n^2 bytes per matrix, first written by the Hessenberg reduction)
+    float* M2 = reinterpret_cast<float*>(B.Z);
+    float* M2T = M2 + (long)batch * n * n;
     if (set_max_dyn_smem((const void*)bal_seq_kernel<T>, smq)) return TRX_ERR_LAUNCH;
     if (hipMemsetAsync(need, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
     TRX_LAUNCH((bal_rownorm_kernel<T>), dim3(cdiv_i(n, 4), batch), dim3(256), 0, s, (const cx<T>*)B.A, n, r2);
     TRX_LAUNCH((bal_colnorm_kernel<T>), dim3(cdiv_i(n, 64), batch), dim3(256), 0, s, (const cx<T>*)B.A, n, c2);
     TRX_LAUNCH((bal_precheck_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const T*)r2, (const T*)c2, n, d, need);
-    TRX_LAUNCH((bal_seq_kernel<T>), dim3(batch), dim3(BST), smq, s, (const cx<T>*)B.A, n, d, (const int*)need, 4);
+    TRX_LAUNCH((bal_sq_kernel<T>), dim3(cdiv_i(n, 32), cdiv_i(n, 32), batch), dim3(256), 0, s, (const cx<T>*)B.A, n, M2, M2T, (const int*)need);
+    TRX_LAUNCH((bal_seq_kernel<T>), dim3(batch), dim3(BST), smq, s, (const float*)M2, (const float*)M2T, n, (const T*)r2, (const T*)c2, d, (const int*)need, 4);
     TRX_LAUNCH((bal_apply_kernel<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, B.A, n, (const T*)d, (const int*)need);
     TRX_CHECK_LAUNCH();
     return TRX_OK;

@@ -993,7 +993,7 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
 // DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it.  (A 64-register build of the fp32
 // kernel -- so that its 4 waves per SIMD fit next to update workgroups -- spilled 45 registers in the band update and changed nothing:
 // profiles/r05_ab/r5h_occupancy.txt.)
-template <class T, bool DBG>
+template <class T, bool DBG, bool FWD>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
                                                         int par, int nslot, int kc, int slot0, int nsteps, int band_on, int* __restrict__ counters, long long* dbg_all = nullptr) {
@@ -1081,24 +1081,14 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         }
         __syncthreads();
         if (dbg) { const long long t1 = clock64(); dbg[12] += t1 - tk0; tk0 = t1; }
-        // The window unitary U lives in REGISTERS: wave sb owns rows UR sb .. UR sb + UR - 1, lane = column.  A chain step multiplies U from
-        // the right by the step's rotations, which act on DISJOINT adjacent column pairs -- for a row held one column per lane that is one
-        // lane-parallel operation with the neighbour lane's value (v_mov_dpp wave_shl / wave_shr), every wave on its own rows, no barrier and
-        // no LDS traffic but the 12 - 24 bytes of the rotation itself.  (Rounds 2 - 5 replayed the logged rotations onto U in LDS after the
-        // chase: one more LDS round trip and one more 16-wave barrier per chain step, ~600 of the ~3800 cycles a chain step cost in all.)
-        constexpr int UR = QW / (WTHREADS / 64);
-        cx<T> u[UR];
-#pragma unroll
-        for (int i = 0; i < UR; ++i) u[i] = cx<T>((UR * sb + i == j) ? T(1) : T(0), T(0));
         // Every phase of a chain step touches WIT element pairs per lane: the loops are fully unrolled with clamped LDS reads issued
         // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
         // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
         // barrier absorbs the skew.)
-        // FORWARDED rotation inputs: the (f, g) of chain step tau + 1 are H[q + 1, q] and H[q + 2, q] -- column q, which this wave's OWN right
-        // rotation of step tau has just produced (rows q + 1, q + 2 = lanes q + 1, q + 2) and which no other bulge touches in between (their
-        // column pairs are disjoint from ours within a step, and left rotations came before).  So the next rotation is generated from
-        // registers (two v_readlane) in the shadow of the step's second barrier instead of an LDS round trip after it: 830 of the 2440
-        // cycles of a chain step were this read + generate (TRX_QR_DEBUG, profiles/r06_ab/r6a_first_call.txt).
+        // FWD -- forwarded rotation inputs: the (f, g) of chain step tau + 1 are H[q + 1, q] and H[q + 2, q] -- column q, which this wave's OWN
+        // right rotation of step tau has just produced (rows q + 1, q + 2 = lanes q + 1, q + 2) and which no other bulge touches in between.
+        // The next rotation is then generated from registers (two v_readlane) before the step's second barrier instead of from an LDS round
+        // trip after it.
         static_assert(WIT == 1, "forwarding reads row q + 1 / q + 2 from lanes q + 1 / q + 2");
         Rot<T> Rnext;
         bool have_next = false;                       // (wave-uniform)
@@ -1108,7 +1098,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             const int q = p - w0;
             const bool first = (p == ilo);
             Rot<T> R;
-            if (active && have_next) {
+            if (FWD && active && have_next) {
                 R = Rnext;
             } else if (active) {
                 cx<T> f, g;
@@ -1140,43 +1130,22 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
             if (dbg) { const long long t1 = clock64(); dbg[17] += t1 - tk0; tk0 = t1; }
             __syncthreads();
             if (dbg) { const long long t1 = clock64(); dbg[18] += t1 - tk0; tk0 = t1; }
-            const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
-            cx<T> xh[WIT], yh[WIT];
             if (active) {
+                const int hi = (q + 2 < ww - 1) ? q + 2 : ww - 1;
+                cx<T> xh[WIT], yh[WIT];
 #pragma unroll
                 for (int it = 0; it < WIT; ++it) {
                     const int row = j + LPB * it;
                     const int rh = row <= hi ? row : hi;
                     xh[it] = Hw[rh * LD + q]; yh[it] = Hw[rh * LD + q + 1];
                 }
-            }
-            {
-                // U <- U G(tau): lane j = column j belongs to bulge sp = (q0 + 1 - j) >> 1 (q0 = bulge 0's column; first column of the pair when
-                // q0 + 1 - j is odd); the rotation comes from the log of this step (every wave has written its entry before the barrier;
-                // bulges that do not move logged the identity).  (x, y) <- (c x + conj(s) y, -s x + c y) for the pair (x, y) = (this lane,
-                // next lane) resp. (previous lane, this lane).
-                const int d = (ilo + tau - w0) + 1 - j;
-                const int sp = d >> 1;
-                const bool in = d >= 0 && sp < QNS;
-                RotCS<T> rc = rlog[(tau - tau0) * QNS + (in ? sp : 0)];
-                if (!in) { rc.c = T(1); rc.s = cx<T>(T(0), T(0)); }
-                const bool firstcol = (d & 1) != 0;
-                const cx<T> coef = firstcol ? conj(rc.s) : cx<T>(-rc.s.x, -rc.s.y);
-#pragma unroll
-                for (int i = 0; i < UR; ++i) {
-                    const cx<T> nx = lane_from_next(u[i]), pv = lane_from_prev(u[i]);
-                    const cx<T> partner = firstcol ? nx : pv;
-                    u[i] = rc.c * u[i] + coef * partner;
-                }
-            }
-            if (active) {
 #pragma unroll
                 for (int it = 0; it < WIT; ++it) {
                     const int row = j + LPB * it;
                     rot_cols(R, xh[it], yh[it]);
                     if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
                 }
-                if (q + 2 <= ww - 1 && p + 1 <= ihi - 1 && tau < tau_end) {
+                if (FWD && q + 2 <= ww - 1 && p + 1 <= ihi - 1 && tau < tau_end) {
                     // the bulge stays inside this window and inside the active block: its next rotation from the new column q
                     Rnext = rotg_fast(bcast_lane(xh[0], q + 1), bcast_lane(xh[0], q + 2));
                     have_next = true;
@@ -1189,35 +1158,70 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (dbg) { dbg[13] += dbg[16] + dbg[17] + dbg[18] + dbg[19] + dbg[20] - dbg[13]; dbg[15] += tau_end - tau0 + 1; tk0 = clock64(); }
         cx<T>* U = Ulog_all + (((long)b * nslot + slot0 + s) * kc + ch) * QW * QW;
         {
-            // chase done: the window goes back to H (through registers: the planes of the band update take over its LDS)
+            // phase 1 done: the window goes back to H, the buffer becomes U = I
             const int c = t & (QW - 1), r4 = t / QW;
             cx<T> hv[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
-            if (t == 0) *sflag = 0;
-            __syncthreads();                             // every thread holds its part of the window: the buffer may be overwritten (planes below)
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int r = r4 + RSTEP * i;
                 if (r < ww && c < ww) H[(long)(w0 + r) * n + w0 + c] = hv[i];
+                Hw[r * LD + c] = cx<T>(r == c ? T(1) : T(0), T(0));
             }
+        }
+        __syncthreads();
+        // phase 2: replay the logged rotations onto U (right multiplications; within a chain step the bulges own disjoint column pairs)
+        for (int tau = tau0; tau <= tau_end; ++tau) {
+            const int p = ilo + tau - 2 * sb;
+            const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
+            if (active) {
+                const int q = p - w0;
+                Rot<T> R;
+                R.c = rlog[(tau - tau0) * QNS + sb].c; R.s = rlog[(tau - tau0) * QNS + sb].s;
+                cx<T> xu[WIT], yu[WIT];
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    const int ru = row < ww ? row : ww - 1;
+                    xu[it] = Hw[ru * LD + q]; yu[it] = Hw[ru * LD + q + 1];
+                }
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int row = j + LPB * it;
+                    rot_cols(R, xu[it], yu[it]);
+                    if (row < ww) { Hw[row * LD + q] = xu[it]; Hw[row * LD + q + 1] = yu[it]; }
+                }
+            }
+            __syncthreads();
         }
         const bool do_band = band_e > w1;            // (workgroup-uniform)
         {
-            // U goes from the registers to the log; for the band update also into split planes over the window's LDS (zero outside ww x ww)
-            int dense = 0;
+            // U goes to the log; for the band update also, through registers, into split planes over the same LDS (zero outside ww x ww)
+            const int c = t & (QW - 1), r4 = t / QW;
+            cx<T> hv[RPT];
 #pragma unroll
-            for (int i = 0; i < UR; ++i) {
-                const int r = UR * sb + i, c = j;
-                cx<T> v = u[i];
-                if (r < ww && c < ww) U[r * QW + c] = v;
-                else v = cx<T>(T(0), T(0));
-                if (do_band) {
-                    Ur[r * MLD + c] = v.x; Ui[r * MLD + c] = v.y;
-                    if ((r >> 4) >= (c >> 4) + 2 && (v.x != T(0) || v.y != T(0))) dense = 1;
+            for (int i = 0; i < RPT; ++i) hv[i] = Hw[(r4 + RSTEP * i) * LD + c];
+            if (c < ww) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = r4 + RSTEP * i;
+                    if (r < ww) U[r * QW + c] = hv[i];
                 }
             }
             if (do_band) {
+                if (t == 0) *sflag = 0;
+                __syncthreads();                         // every thread holds its part of U; the buffer may be overwritten
+                int dense = 0;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = r4 + RSTEP * i;
+                    cx<T> v = hv[i];
+                    if (r >= ww || c >= ww) v = cx<T>(T(0), T(0));
+                    Ur[r * MLD + c] = v.x; Ui[r * MLD + c] = v.y;
+                    if ((r >> 4) >= (c >> 4) + 2 && (v.x != T(0) || v.y != T(0))) dense = 1;
+                }
                 if (dense) *sflag = 1;
                 __syncthreads();
             }
@@ -1271,7 +1275,7 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256, APPLY_MIN_WG(T)) void apply_links_kernel(cx<T>* __restrict__ Aall, cx<T>* __restrict__ Zall, long mstride, int n,
                                                           const QrLink* __restrict__ links_all, const cx<T>* __restrict__ Ulog_all,
                                                           const cx<T>* __restrict__ Udense_all, unsigned* __restrict__ work, int nslot, int kc,
-                                                          int q0, int nq, int spw, int units, int band_on, int g_lo, int g_hi) {
+                                                          int q0, int nq, int spw, int units, int band_on) {
     TRX_DYN_SMEM(smem);
     T* Ur = reinterpret_cast<T*>(smem);      // [QW][MLD]
     T* Ui = Ur + QW * MLD;
@@ -1305,14 +1309,13 @@ __global__ __launch_bounds__(256, APPLY_MIN_WG(T)) void apply_links_kernel(cx<T>
                 nL = n > e ? (n - e + 15) >> 4 : 0;
                 if (MODE == 2) { nR = (w0 + 15) >> 4; nZ = (n + 15) >> 4; }
                 S = nL + nR + nZ;
-                if (MODE == 0) { S = S < g_hi ? S : g_hi; }        // strips [g_lo, g_hi) of the link only (near / far part of the left update)
-                g0 = (MODE == 0 ? g_lo : 0) + gx * (4 * spw);
+                g0 = gx * (4 * spw);
                 if (g0 >= S) continue;
             } else {
                 if (row0 >= (isZ ? n : w0)) continue;
             }
             if (gx == 0 && t == 0)      // algorithmic work of this link's update, in units of 4096 complex MACs
-                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (MODE == 2 ? 2L * n - ww : (long)(16 * (S - g_lo) < n - e - 16 * g_lo ? 16 * (S - g_lo) : n - e - 16 * g_lo)))) >> 12));
+                atomicAdd(work, (unsigned)(((long)ww * ww * (MODE == 1 ? (long)((units & 1) ? w0 : 0) + ((units & 2) ? n : 0) : (MODE == 2 ? 2L * n - ww : (long)(n > e ? n - e : 0)))) >> 12));
             const cx<T>* U = MODE == 2 ? Udense_all + (long)b * QW * QW : Ulog_all + (((long)b * nslot + qq) * kc + ch) * QW * QW;
             // Per link: (1) ALL global loads up front -- the 16 U elements of this thread and the first strip's 64 x 16 block (both only depend on
             // what this wave itself stored for the previous link) -- (2) barrier: the previous link's readers are done with the planes, (3) U
@@ -1404,7 +1407,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0, far = 0, near = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0, fwd = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1427,7 +1430,7 @@ static QrKnobs& qr_knobs() {
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
         q.defer = geti("TRX_QR_DEFER", 0, 2, 0);              // right / Z update: 0 automatic, 1 behind every (super-)step, 2 once per sweep
-        q.far = geti("TRX_QR_FAR", 0, 2, 0);                  // left update beyond the next launch's columns on a second stream per group: 0 automatic (on), 1 off, 2 on
+        q.fwd = geti("TRX_QR_FWD", 0, 1, 0);                  // 1: the chase generates a bulge's next rotation from registers (forwarded) -- A/B of round 6
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1486,8 +1489,6 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
     else if (s == "qr_defer") { slot = &k.defer; hi = 2; }
-    else if (s == "qr_far") { slot = &k.far; hi = 2; }
-    else if (s == "qr_near") { slot = &k.near; hi = 4096; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1515,7 +1516,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
         if (stt == 0) {
             const size_t sma_max = 160 * 1024 - 512;     // (the link records depend on n: opt in to the largest size once)
-            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) ||
+            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true, false>, smw) ||
+                  set_max_dyn_smem((const void*)qr_window_kernel<T, false, true>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true, true>, smw) ||
                   set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma_max) ||
                   set_max_dyn_smem((const void*)apply_links_kernel<T, 2>, sma_max) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
@@ -1540,17 +1542,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // window steps per launch: super-steps need one chain per sweep (several chains advance in lock-step, one window step per launch)
     const int super = kc == 1 ? (K.super ? K.super : (sizeof(T) == 4 ? 4 : 8)) : 1;          // measured: fp32 4 (2 / 8 within 0.5 %), fp64 8 (28.4 vs 28.1 layer-solves/s on the all-fp64 route)
     const bool defer = kc == 1 && K.defer != 1;
-    // The left update of a super-step in two parts.  What the NEXT launch of the chain needs of it are only the columns its windows and its
-    // in-kernel band reach: the first `gnear` 16-column strips right of this launch's band (a launch advances by at most super * 61 columns).
-    // Those stay on the group's stream (near part: a quarter of a millisecond of chain per iteration instead of two); the rest -- up to 1900
-    // columns, 76 us of chip-filling matrix-core work alone and 207 us in situ, eleven times per iteration on the critical path of rounds
-    // 4 - 5 -- goes to a SECOND stream of the group and runs under the next chase launch (far part).  Orders kept by events: far(S) after
-    // chase(S) (unitaries, band), near(S + 1) after far(S) (same strips, links in order), the sweep's deferred right / Z update and everything
-    // after it behind the last far part.
-    const bool far_on = defer && K.far != 1 && batch >= 2;
-    // (knob qr_near: strips of the near part, for tests of the far path on matrices too small to have one -- only safe where launches run in
-    // issue order, i.e. on the CPU kernel-logic emulator)
-    const int gnear = K.near ? K.near : cdiv_i(super * (QW - 1), 16) + 1;
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1560,8 +1551,6 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     constexpr int MAXG = 8;
     struct Group {
         QrLane lane;           // streams + events
-        QrLane far;            // second stream of the group: the part of the left update the next launch does not wait for (see issue_sweep)
-        bool has_far, far_pending;
         hipStream_t s;
         int b0, nb;
         int* summary;          // device, 16 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
@@ -1576,12 +1565,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     int ngroups = K.groups ? K.groups : (batch >= 64 ? 4 : (batch >= 8 ? 2 : 1));
     if (ngroups > batch) ngroups = batch;
     Group grp[MAXG];
-    for (int g = 0; g < MAXG; ++g) { grp[g].has_far = false; grp[g].far_pending = false; }
     int rc = TRX_OK, dev = 0, nlanes = 0;
     (void)hipGetDevice(&dev);
     QrLane fork;
-    const bool need_fork = ngroups > 1 || far_on;
-    if (need_fork) {
+    if (ngroups > 1) {
         if (!lane_checkout(dev, false, fork) || hipEventRecord(fork.ev, s) != hipSuccess) return TRX_ERR_LAUNCH;
     }
     for (int g = 0; g < ngroups; ++g) {
@@ -1598,14 +1585,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.work[0] = G.work[1] = G.work[2] = G.work[3] = 0;
         G.par = 0;
         G.g = g;
-        G.has_far = false; G.far_pending = false;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
         ++nlanes;
-        if (far_on) {
-            if (!lane_checkout(dev, true, G.far)) { rc = TRX_ERR_LAUNCH; break; }
-            G.has_far = true;
-            if (hipStreamWaitEvent(G.far.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }      // (everything the caller queued before this call)
-        }
         G.s = g == 0 ? s : G.lane.s;
         if (g > 0 && hipStreamWaitEvent(G.s, fork.ev, 0) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
@@ -1658,49 +1639,34 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         for (int q = 0; q < nwin;) {
             const int ns = q == 0 ? 1 : (nwin - q < super ? nwin - q : super);
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
-              if (qr_debug && G.b0 == 0) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbg_dev);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, (long long*)nullptr); }
+              const bool dbgk = qr_debug && G.b0 == 0;
+              long long* dbp = dbgk ? dbg_dev : (long long*)nullptr;
+#define TRX_QRW_LAUNCH(D, F) TRX_LAUNCH((qr_window_kernel<T, D, F>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp)
+              if (K.fwd) { if (dbgk) TRX_QRW_LAUNCH(true, true); else TRX_QRW_LAUNCH(false, true); }
+              else { if (dbgk) TRX_QRW_LAUNCH(true, false); else TRX_QRW_LAUNCH(false, false); }
+#undef TRX_QRW_LAUNCH
+            }
             G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
               if (q == 0) {      // the dense link of slot 0, if there is one: left | right-H | Z, up to 3 n / 16 + 3 strips
                   const int du = cdiv_i(3 * nstrip + 3, 4 * spw);
-                  TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on, 0, 1 << 30);
+                  TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on);
               }
               const int units = cdiv_i(nstrip + 1, 4 * spw);
-              if (G.has_far && q > 0) {
-                  // near part on the group's stream (after the far part of the launch before: same strips, links in order) ...
-                  const int un = cdiv_i(gnear, 4 * spw);
-                  if (hipEventRecord(G.far.evs[0], G.s) != hipSuccess) return false;                            // "chase(S) done"
-                  if (G.far_pending && hipStreamWaitEvent(G.s, G.far.ev, 0) != hipSuccess) return false;        // far(S - 1) done
-                  TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * un, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, un, band_on, 0, gnear);
-                  // ... far part on the second stream, under the next chase launch
-                  if (hipStreamWaitEvent(G.far.s, G.far.evs[0], 0) != hipSuccess) return false;
-                  { ProfScope pf(PROF_QR_APPLY_LEFT, G.far.s, 0, 0);
-                    TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.far.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on, gnear, 1 << 30); }
-                  if (hipEventRecord(G.far.ev, G.far.s) != hipSuccess) return false;
-                  G.far_pending = true;
-              } else {
-                  TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on, 0, 1 << 30);
-              }
+              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
               // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
               // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
               if (!defer)
-                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on, 0, 1 << 30); }
+                  TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
             q += ns;
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
         // deflation), so it cannot run beside it.
-        if (G.far_pending) {
-            // join: the far parts touch rows of this sweep's windows in the columns right of them -- the rows x columns the deferred right
-            // update below (and the next prepare, and the next sweep) work on
-            if (hipStreamWaitEvent(G.s, G.far.ev, 0) != hipSuccess) return false;
-            G.far_pending = false;
-        }
         if (defer) {
             ProfScope p(PROF_QR_APPLY_RIGHT, G.s, 0, 0);
-            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on, 0, 1 << 30);
+            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk + 4, nslot, kc, 0, nwin, 1, 3, band_on);
         }
         return true;
     };
@@ -1774,13 +1740,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         }
         lane_return(G.lane);
     }
-    for (int g = 0; g < ngroups; ++g)
-        if (grp[g].has_far) {
-            // every far part has been joined into its group's stream above; the lane goes back to the pool with an empty queue
-            if (hipStreamSynchronize(grp[g].far.s) != hipSuccess) rc = rc ? rc : TRX_ERR_LAUNCH;
-            lane_return(grp[g].far);
-        }
-    if (need_fork) lane_return(fork);
+    if (ngroups > 1) lane_return(fork);
     if (rc) return rc;
     if (qr_debug) {
         long long h[24];

@@ -118,8 +118,8 @@ __global__ void refine_scan_reduce_kernel(const T* __restrict__ part, T* __restr
 //     |E_ij| + |E_ji| > rho |lambda_j - lambda_i|      (rho = 0.1; equal eigenvalues included).
 // A global distance threshold would lump together every pair of close eigenvalues -- at n = 1922 the fp32 start leaves max |E| = 4e-4 and
 // the spectrum has gaps of 2e-3 -- although close eigenvalues are, as a rule, hardly coupled at all: with this criterion the bench operator
-// has NO coupled pair, a square meta-atom exactly its degenerate pairs.  One thread per index i walks j > i; a coupled pair marks both
-// indices and appends an edge to the matrix's list (capacity REC; the count keeps running so that an overflow is seen).
+// has NO coupled pair, a square meta-atom exactly its degenerate pairs.  A coupled pair (i < j) marks both indices and appends an edge to the
+// matrix's list (capacity REC; the count keeps running so that an overflow is seen).
 constexpr int RCM = 32;       // largest cluster diagonalised here
 constexpr int RCK = 1024;     // most clusters per matrix
 constexpr int REC = REFINE_EDGE_CAP;     // most coupled pairs (edges) per matrix
@@ -135,26 +135,40 @@ struct RefineClusters {       // per matrix (at most REFINE_CLUSTER_BYTES)
 };
 static_assert(sizeof(RefineClusters<double>) <= REFINE_CLUSTER_BYTES, "cluster table");
 
+// Tiled: a workgroup takes the 32 x 32 tile pair (I, J), J >= I, of E -- E[I, J] and E[J, I], both read row-wise (coalesced) into LDS -- and
+// tests its 1024 index pairs (the one-thread-per-index walk of the first version read E[i, :] with a stride of n between lanes: 9.9 ms per
+// call at the bench shape against ~1 ms for one pass over E).
+constexpr int RCT = 32;
 template <class T>
 __global__ __launch_bounds__(256) void refine_cluster_kernel(const cx<float>* __restrict__ Eall, const cx<T>* __restrict__ lam, int n, int* __restrict__ coupled,
                                                              int* __restrict__ edges, int* __restrict__ ecount) {
-    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float a_ij[RCT][RCT + 1], a_ji[RCT][RCT + 1];          // |E[I0 + r, J0 + c]|_1 and |E[J0 + r, I0 + c]|_1
+    __shared__ cx<T> li[RCT], lj[RCT];
+    const int b = blockIdx.z, I0 = blockIdx.y * RCT, J0 = blockIdx.x * RCT;
+    if (J0 < I0) return;                                               // (workgroup-uniform) upper triangle of tile pairs only
     const cx<float>* E = Eall + (long)b * n * n;
-    const cx<T>* l = lam + (long)b * n;
+    const int t = threadIdx.x, c = t & (RCT - 1), r0 = t / RCT;        // 8 rows per pass
+    for (int r = r0; r < RCT; r += 256 / RCT) {
+        const int i = I0 + r, j = J0 + c;
+        a_ij[r][c] = (i < n && j < n) ? abs1(E[(long)i * n + j]) : 0.f;
+        const int i2 = J0 + r, j2 = I0 + c;
+        a_ji[r][c] = (i2 < n && j2 < n) ? abs1(E[(long)i2 * n + j2]) : 0.f;
+    }
+    if (t < RCT) li[t] = I0 + t < n ? lam[(long)b * n + I0 + t] : cx<T>(T(0), T(0));
+    else if (t < 2 * RCT) lj[t - RCT] = J0 + t - RCT < n ? lam[(long)b * n + J0 + t - RCT] : cx<T>(T(0), T(0));
+    __syncthreads();
     const T rho = T(0.1);
-    const cx<T> li = l[i];
-    bool mine = false;
-    for (int j = i + 1; j < n; ++j) {
-        const T c = (T)(abs1(E[(long)i * n + j]) + abs1(E[(long)j * n + i]));
-        if (!(c <= rho * abs1(l[j] - li))) {
-            mine = true;
+    for (int r = r0; r < RCT; r += 256 / RCT) {
+        const int i = I0 + r, j = J0 + c;
+        if (i >= n || j >= n || j <= i) continue;
+        const T cpl = (T)(a_ij[r][c] + a_ji[c][r]);                   // |E_ij| + |E_ji|
+        if (!(cpl <= rho * abs1(lj[c] - li[r]))) {
+            coupled[(long)b * n + i] = 1;
             coupled[(long)b * n + j] = 1;
             const int e = atomicAdd(&ecount[b], 1);
             if (e < REC) { edges[((long)b * REC + e) * 2] = i; edges[((long)b * REC + e) * 2 + 1] = j; }
         }
     }
-    if (mine) coupled[(long)b * n + i] = 1;
 }
 
 // Schur form + eigenvectors of a dense m x m block (m <= RCM), serial: Hessenberg by Givens rotations, explicitly shifted QR
@@ -465,7 +479,7 @@ int eig_refine(hipStream_t s, const RefineBuffers<T>& R, const cx<T>* A, const c
         TRX_LAUNCH((refine_scan_kernel<T>), dim3(RSPLIT, batch), dim3(256), 0, s, (const cx<float>*)R.E32, n, w, R.d0, R.scan_part);
         TRX_LAUNCH((refine_scan_reduce_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const T*)R.scan_part, R.eoff, R.lmax, R.flags, batch);
         if (hipMemsetAsync(R.partner, 0, sizeof(int) * cntw, s) != hipSuccess || hipMemsetAsync(R.ecount, 0, sizeof(int) * batch, s) != hipSuccess) return TRX_ERR_LAUNCH;
-        TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, 256), batch), dim3(256), 0, s, (const cx<float>*)R.E32, (const cx<T>*)w, n, R.partner, R.edges, R.ecount);
+        TRX_LAUNCH((refine_cluster_kernel<T>), dim3(cdiv_i(n, RCT), cdiv_i(n, RCT), batch), dim3(256), 0, s, (const cx<float>*)R.E32, (const cx<T>*)w, n, R.partner, R.edges, R.ecount);
         TRX_LAUNCH((refine_solve_clusters_kernel<T>), dim3(batch), dim3(64), sm_cl, s, (const cx<float>*)R.E32, n, w, (const cx<T>*)R.d0, (const int*)R.partner,
                    (const int*)R.edges, (const int*)R.ecount, R.clus, (RefineClusters<T>*)R.tab, R.flags, R.flags + batch + 1);
         int host_cnt[2] = {0, 0};                         // {flagged matrices, clusters rotated in this step}
