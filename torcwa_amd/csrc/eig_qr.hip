@@ -990,24 +990,106 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
     }
 }
 
+// Fused launches (qr_window_kernel): band end of a launch whose predecessor's band ended at e_prev -- every window of the launch and the first
+// one of the next end left of it, because the predecessor's band already reached the first window of this launch and a window step advances
+// by at most QW - 2 k - 1 columns -- and the number of 16-column strips between the two, which the chase workgroup brings up to date itself.
+__device__ __forceinline__ int fused_band_end(int e_prev, int k, int nsteps, int n) {
+    const int e = e_prev + nsteps * (QW - 2 * k - 1);
+    return e > n ? n : e;
+}
+__device__ __forceinline__ int fused_catchup_strips(int e_prev, int k, int nsteps, int n) {
+    const int e = fused_band_end(e_prev, k, nsteps, n);
+    return e > e_prev ? (e - e_prev + 15) >> 4 : 0;
+}
+
+// U^H from the left for the chase links lks[0], lks[kc], ... (pnq of them, one chain) on the 16-column strips a0 = e + 16 g of the columns right
+// of their launch's band (e: recorded in the links), for g = g0 + wave, + gs, ... < g1; one strip per wave and pass, by the lean band routine
+// of the window kernel.  All 1024 threads of the workgroup; U is staged per link into split planes at the start of the dynamic LDS.
+template <class T>
+__device__ void left_links_strips(cx<T>* __restrict__ H, int n, const QrLink* __restrict__ lks, int kc, const cx<T>* __restrict__ Ulog, int pnq, T* Ur, T* Ui,
+                                  int* vote, int g0, int g1, int gs, int band_on, unsigned* __restrict__ work) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int UPT = QW * QW / WTHREADS;
+    for (int i = 0; i < pnq; ++i) {
+        const QrLink l = lks[(long)i * kc];
+        const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
+        const int e = __builtin_amdgcn_readfirstlane(l.e);
+        const int ww = w1 - w0;
+        if (kind != QRL_CHASE || ww <= 0) continue;
+        const int nL = n > e ? (n - e + 15) >> 4 : 0;
+        const int lim = g1 < nL ? g1 : nL;
+        if (g0 >= lim) continue;                             // (workgroup-uniform)
+        const cx<T>* U = Ulog + (long)i * kc * QW * QW;
+        cx<T> ureg[UPT];
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
+            ureg[q] = U[(k < ww ? k : ww - 1) * QW + (c < ww ? c : ww - 1)];
+        }
+        if (t == 0) vote[i & 1] = 0;
+        __syncthreads();                                     // the previous link's readers are done with the planes
+        int dense = 0;
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
+            cx<T> u = ureg[q];
+            if (k >= ww || c >= ww) u = cx<T>(T(0), T(0));
+            Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+            if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
+        }
+        if (dense) vote[i & 1] = 1;
+        __syncthreads();
+        const bool band = band_on && vote[i & 1] == 0;
+        int mine = 0;
+        for (int g = g0 + wave; g < lim; g += gs) {
+            SlabStrip<T> d;
+            d.X = H; d.side = 0; d.a0 = e + 16 * g; d.lim = n;
+            band_left_strip<T>(Ur, Ui, d, n, w0, ww, lane, band);
+            ++mine;
+        }
+        if (lane == 0 && mine > 0) atomicAdd(work, (unsigned)(((long)ww * ww * 16 * mine) >> 12));       // units of 4096 complex MACs
+    }
+    __syncthreads();                                         // planes free again
+}
+
 // DBG: cycle counters of matrix 0, chain 0 (TRX_QR_DEBUG); the production instantiation carries none of it.  (A 64-register build of the fp32
 // kernel -- so that its 4 waves per SIMD fit next to update workgroups -- spilled 45 registers in the band update and changed nothing:
 // profiles/r05_ab/r5h_occupancy.txt.)
-template <class T, bool DBG, bool FWD>
+template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
-                                                        int par, int nslot, int kc, int slot0, int nsteps, int band_on, int* __restrict__ counters, long long* dbg_all = nullptr) {
+                                                        int par, int nslot, int kc, int slot0, int nsteps, int band_on, int* __restrict__ counters, long long* dbg_all,
+                                                        int prev_q0, int prev_nq, unsigned* __restrict__ work) {
+    // FUSED LAUNCH (one chain per sweep, prev_nq > 0): besides the chase workgroups (blockIdx.x < kc) the grid carries FAR workgroups
+    // (blockIdx.x >= kc) that apply the left update of the PREVIOUS launch's links to the columns this launch's chase does not touch -- the
+    // work that sat, as a launch of its own, between two chase launches of the chain in rounds 4 - 5 (76 us alone, 207 us in situ, eleven
+    // times per iteration) now runs beside the chase, on other compute units.  The columns the chase does reach -- [e_prev, e_this), e = the
+    // band end of a launch -- get the previous links from the chase workgroup itself before its first window (catch-up), so that every
+    // strip still sees the links in order.  No stream, no event, one launch fewer per super-step.
     TRX_DYN_SMEM(smem);
-    long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
-    long long tk0 = dbg ? clock64() : 0;
     constexpr int LD = QW + 1;
     cx<T>* Hw = reinterpret_cast<cx<T>*>(smem);      // [QW][LD]   phase 1: H window;  phase 2: U
     RotCS<T>* rlog = reinterpret_cast<RotCS<T>*>(Hw + QW * LD);      // [WMAXS][QNS]
     QrState& sst = *reinterpret_cast<QrState*>(rlog + WMAXS * QNS);
-    int* sflag = reinterpret_cast<int*>(&sst + 1);                   // "U has a nonzero outside the band"
+    int* sflag = reinterpret_cast<int*>(&sst + 1);                   // [0] "U has a nonzero outside the band"; [1], [2]: the same for the links of left_links_strips
     T* Ur = reinterpret_cast<T*>(smem);              // [QW][MLD] x 2: split planes of U for the band update, over Hw | rlog (both dead by then)
     T* Ui = Ur + QW * MLD;
     static_assert(sizeof(T) * 2 * QW * MLD <= sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS, "planes fit over window + log");
+    if ((int)blockIdx.x >= kc) {
+        const int b = blockIdx.y, fx = (int)blockIdx.x - kc, nfar = (int)gridDim.x - kc;
+        if (threadIdx.x == 0) sst = st_all[b];
+        __syncthreads();
+        // (Nothing here may depend on the chase position: the chase workgroup of this launch rewrites it when it is done, and a far workgroup
+        // can be scheduled late.  The split of the strips is a function of the previous launch's band end and of constants of the sweep.)
+        const QrLink* pl = links_all + ((long)b * nslot + prev_q0) * kc;                   // (chain 0: kc == 1 in fused launches)
+        const int gc = fused_catchup_strips(pl[0].e, sst.k[0], nsteps, n);                   // strips the chase workgroup catches up on itself
+        left_links_strips<T>(Aall + (long)b * mstride, n, pl, kc, Ulog_all + ((long)b * nslot + prev_q0) * kc * QW * QW, prev_nq, Ur, Ui, sflag + 1,
+                             gc + 16 * fx, 1 << 30, 16 * nfar, band_on, work);
+        return;
+    }
+    long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
+    long long tk0 = dbg ? clock64() : 0;
     const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
     if (t == 0) sst = st_all[b];
     __syncthreads();
@@ -1034,6 +1116,17 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
     const cx<T> shift = (sb < k) ? shifts_all[((long)b * QKC + ch) * QNS + sb] : cx<T>(T(0), T(0));
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;      // window elements per thread, row stride between them
+    if (prev_nq > 0) {
+        // catch-up of a fused launch: the previous launch's links on the strips between its band end and ours (see the kernel head), whether
+        // or not the chain still moves; our own band then ends where the far workgroups begin
+        const QrLink* pl = links_all + ((long)b * nslot + prev_q0) * kc + ch;
+        if (pl[0].kind == QRL_CHASE) {
+            const int e_prev = pl[0].e;
+            const int gc = fused_catchup_strips(e_prev, st.k[0], nsteps, n);
+            left_links_strips<T>(H, n, pl, kc, Ulog_all + (((long)b * nslot + prev_q0) * kc + ch) * QW * QW, prev_nq, Ur, Ui, sflag + 1, 0, gc, WTHREADS / 64, band_on, work);
+            band_e = fused_band_end(e_prev, st.k[0], nsteps, n);
+        }
+    }
     for (int s = 0; s < nsteps; ++s) {
         const int tau0 = tau_cur;
         bool move = chasing && tau0 <= tau_last;
@@ -1085,28 +1178,20 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         // up front and guarded writes, so a phase costs one LDS round trip.  (Computing the next rotation right after the H part of
         // the right phase, to overlap it with the U part, was tried and is not faster: hipcc serialises the two and the second
         // barrier absorbs the skew.)
-        // FWD -- forwarded rotation inputs: the (f, g) of chain step tau + 1 are H[q + 1, q] and H[q + 2, q] -- column q, which this wave's OWN
-        // right rotation of step tau has just produced (rows q + 1, q + 2 = lanes q + 1, q + 2) and which no other bulge touches in between.
-        // The next rotation is then generated from registers (two v_readlane) before the step's second barrier instead of from an LDS round
-        // trip after it.
-        static_assert(WIT == 1, "forwarding reads row q + 1 / q + 2 from lanes q + 1 / q + 2");
-        Rot<T> Rnext;
-        bool have_next = false;                       // (wave-uniform)
+        // (Forwarding the next rotation's inputs from this wave's own right rotation -- two v_readlane instead of the LDS read behind the step's
+        // second barrier -- was measured in round 6: QR phase 939 against 919 ms at batch 128, 440 against 416 ms at batch 16.  Not in the tree.)
         for (int tau = tau0; tau <= tau_end; ++tau) {
             const int p = ilo + tau - 2 * sb;
             const bool active = (sb < k) && (p >= ilo) && (p <= ihi - 1);
             const int q = p - w0;
             const bool first = (p == ilo);
             Rot<T> R;
-            if (FWD && active && have_next) {
-                R = Rnext;
-            } else if (active) {
+            if (active) {
                 cx<T> f, g;
                 if (first) { f = Hw[q * LD + q] - shift; g = Hw[(q + 1) * LD + q]; }
                 else { f = Hw[q * LD + q - 1]; g = Hw[(q + 1) * LD + q - 1]; }
                 R = rotg_fast(f, g);
             } else { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = cx<T>(T(0), T(0)); }
-            have_next = false;
             if (j == 0) { rlog[(tau - tau0) * QNS + sb].c = R.c; rlog[(tau - tau0) * QNS + sb].s = R.s; }
             wave_sync();                                  // all lanes have read (f, g) before any lane overwrites them
             if (dbg) { const long long t1 = clock64(); dbg[16] += t1 - tk0; tk0 = t1; }
@@ -1144,11 +1229,6 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
                     const int row = j + LPB * it;
                     rot_cols(R, xh[it], yh[it]);
                     if (row <= hi) { Hw[row * LD + q] = xh[it]; Hw[row * LD + q + 1] = yh[it]; }
-                }
-                if (FWD && q + 2 <= ww - 1 && p + 1 <= ihi - 1 && tau < tau_end) {
-                    // the bulge stays inside this window and inside the active block: its next rotation from the new column q
-                    Rnext = rotg_fast(bcast_lane(xh[0], q + 1), bcast_lane(xh[0], q + 2));
-                    have_next = true;
                 }
             }
             if (dbg) { const long long t1 = clock64(); dbg[19] += t1 - tk0; tk0 = t1; }
@@ -1407,7 +1487,7 @@ __global__ void qr_collect_info_kernel(const QrState* __restrict__ st, int* __re
 
 // ---- host-side runtime shared by all calls: tuning knobs resolved ONCE, internal streams / events pooled --------------------
 struct QrKnobs {
-    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0, fwd = 0;
+    int groups = 0, spw = 0, aed = 0, nibble = 100, moves = QAED_MOVES, chains = 0, band = 0, rotb = 0, super = 0, defer = 0, fuse = 0;
     bool debug = false;
 };
 static QrKnobs& qr_knobs() {
@@ -1430,7 +1510,7 @@ static QrKnobs& qr_knobs() {
         q.rotb = geti("TRX_QR_ROTB", 0, 1, 0);               // 1: rotations of the in-LDS Schur solver broadcast by ds_bpermute (round-3 code), else v_readlane
         q.super = geti("TRX_QR_SUPER", 1, QSUPER, 0);       // window steps per launch (fp32, one chain per sweep); 0 = automatic
         q.defer = geti("TRX_QR_DEFER", 0, 2, 0);              // right / Z update: 0 automatic, 1 behind every (super-)step, 2 once per sweep
-        q.fwd = geti("TRX_QR_FWD", 0, 1, 0);                  // 1: the chase generates a bulge's next rotation from registers (forwarded) -- A/B of round 6
+        q.fuse = geti("TRX_QR_FUSE", 0, 2, 0);                // fused launches (chase + far part of the previous launch's left update): 0 automatic (on), 1 off, 2 on
         q.debug = getenv("TRX_QR_DEBUG") != nullptr;
         return q;
     }();
@@ -1489,6 +1569,7 @@ int qr_set_knob(const char* key, int value) {
     else if (s == "slab_band") { slot = &k.band; hi = 2; }
     else if (s == "qr_super") { slot = &k.super; hi = QSUPER; }
     else if (s == "qr_defer") { slot = &k.defer; hi = 2; }
+    else if (s == "qr_fuse") { slot = &k.fuse; hi = 2; }
     else return TRX_ERR_ARG;
     if (value < lo || value > hi || (slot == &k.spw && value == 3) || (slot == &k.aed && value != 0 && value < 16)) return TRX_ERR_ARG;
     *slot = value;
@@ -1516,8 +1597,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         int& stt = attr_state[dev_attr & 63][sizeof(T) == 8];
         if (stt == 0) {
             const size_t sma_max = 160 * 1024 - 512;     // (the link records depend on n: opt in to the largest size once)
-            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true, false>, smw) ||
-                  set_max_dyn_smem((const void*)qr_window_kernel<T, false, true>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true, true>, smw) ||
+            const int r = set_max_dyn_smem((const void*)qr_window_kernel<T, false>, smw) || set_max_dyn_smem((const void*)qr_window_kernel<T, true>, smw) ||
                   set_max_dyn_smem((const void*)apply_links_kernel<T, 0>, sma_max) || set_max_dyn_smem((const void*)apply_links_kernel<T, 1>, sma_max) ||
                   set_max_dyn_smem((const void*)apply_links_kernel<T, 2>, sma_max) ||
                   set_max_dyn_smem((const void*)qr_prepare_kernel<T, false>, smp_of(SM)) || set_max_dyn_smem((const void*)qr_prepare_kernel<T, true>, smp_of(SM));
@@ -1542,6 +1622,8 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // window steps per launch: super-steps need one chain per sweep (several chains advance in lock-step, one window step per launch)
     const int super = kc == 1 ? (K.super ? K.super : (sizeof(T) == 4 ? 4 : 8)) : 1;          // measured: fp32 4 (2 / 8 within 0.5 %), fp64 8 (28.4 vs 28.1 layer-solves/s on the all-fp64 route)
     const bool defer = kc == 1 && K.defer != 1;
+    const bool fuse = defer && K.fuse != 1;                  // fused launches: see qr_window_kernel
+    const int far_wgs = cdiv_i(cdiv_i(n, 16), WTHREADS / 64);       // far workgroups per matrix: 16 strips each, all strips in one pass
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1636,15 +1718,17 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         unsigned* wk = (unsigned*)(G.summary + 3);
         // slot 0 on its own: it may carry the dense link of an AED window / a finished block (all sides at once: up to 3 n / 16 + 3 strips),
         // which must be applied before the chase starts; then super-steps of `super` window steps + ONE left update over their links
+        int prev_q = 0, prev_ns = 0;
         for (int q = 0; q < nwin;) {
             const int ns = q == 0 ? 1 : (nwin - q < super ? nwin - q : super);
             { ProfScope p(PROF_QR_WINDOW, G.s, 0, 0);
               const bool dbgk = qr_debug && G.b0 == 0;
               long long* dbp = dbgk ? dbg_dev : (long long*)nullptr;
-#define TRX_QRW_LAUNCH(D, F) TRX_LAUNCH((qr_window_kernel<T, D, F>), dim3(kc, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp)
-              if (K.fwd) { if (dbgk) TRX_QRW_LAUNCH(true, true); else TRX_QRW_LAUNCH(false, true); }
-              else { if (dbgk) TRX_QRW_LAUNCH(true, false); else TRX_QRW_LAUNCH(false, false); }
-#undef TRX_QRW_LAUNCH
+              // fused launch: the far part of the previous launch's left update rides along (not behind slot 0, whose left update is a launch of its own)
+              const int pq = (fuse && q > 1) ? prev_q : 0, pn = (fuse && q > 1) ? prev_ns : 0;
+              const int gx = kc + (pn > 0 ? far_wgs : 0);
+              if (dbgk) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk);
             }
             G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
@@ -1653,13 +1737,23 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
                   TRX_LAUNCH((apply_links_kernel<T, 2>), dim3(du, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, 0, 1, spw, du, band_on);
               }
               const int units = cdiv_i(nstrip + 1, 4 * spw);
-              TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
+              // fused: the left update of a launch's links is done by the NEXT launch (catch-up + far workgroups) or, for the last launch of
+              // the sweep, by the launch behind the loop
+              if (!fuse || q == 0)
+                  TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, spw, units, band_on);
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
               // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
               // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
               if (!defer)
                   TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
+            prev_q = q; prev_ns = ns;
             q += ns;
+        }
+        if (fuse && prev_q > 0) {
+            // the left update of the sweep's last launch
+            ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
+            const int units = cdiv_i(nstrip + 1, 4 * spw);
+            TRX_LAUNCH((apply_links_kernel<T, 0>), dim3(kc * units, G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, prev_q, prev_ns, spw, units, band_on);
         }
         // deferred right / Z update of all chase links of this sweep: ONE launch.  In line on the group's stream: the prepare kernel that
         // follows may place its AED window on rows these links' updates still have to reach (the active block can end anywhere after a
