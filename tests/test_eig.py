@@ -206,6 +206,32 @@ def test_eig_multiple_bulge_chains(backend, chains):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-13), (np.complex64, 5e-6)])
+@pytest.mark.parametrize("fold,spacing", [(36, 3e-9), (36, 0.0), (70, 0.0)])
+def test_eig_large_cluster_of_equal_eigenvalues(backend, dtype, tol, fold, spacing):
+    """A normal matrix with a 36- / 70-fold (nearly) equal eigenvalue through the Schur pipeline (knob eig_vec = 1).  Inside such a cluster the
+    AED's reordering meets rotation inputs like |f| ~ 1e-100 next to |g| ~ 1e-60: |f|^2 (|f|^2 + |g|^2) underflowed in the fast rotation
+    generator, 1 / sqrt(0) = inf, and the whole result was NaN with info = n (rounds 1 - 5; found in round 6 through the fp64 fallback of the
+    mixed route).  The generator now rescales by a power of two when the product leaves the fp64 range."""
+    be = get_backend(backend)
+    n = 100 if backend == "emu" else 300
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    lam = 2.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    lam[:fold] = (1.5 - 0.5j) + spacing * np.arange(fold)
+    A = ((Q * lam[None, :]) @ Q.conj().T)[None].astype(dtype)
+    try:
+        _set_knobs(be, eig_vec=1)
+        w, V, info = run_eig(be, A)
+    finally:
+        _set_knobs(be, eig_vec=0)
+    assert info[0] == 0
+    res = np.abs(A[0].astype(np.complex128) @ V[0] - V[0] * w[0][None, :]).max() / np.abs(A[0]).max()
+    assert res < tol * 10, res
+    assert match_eigs(w[0], lam) / np.abs(lam).max() < tol * 100
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_eig_nonfinite_input_fails_fast(backend):
     """A NaN in the input cannot converge: info reports the failure (LAPACK style) instead of iterating to the sweep limit."""
     be = get_backend(backend)

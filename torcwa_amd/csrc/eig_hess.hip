@@ -95,10 +95,15 @@ __global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall,
     const cx<T> alpha = bcol[x0];
     cx<T> tau_c, scale;
     T beta;
-    if (xn2 == T(0) && alpha.y == T(0)) {
+    // |alpha|^2 + |x|^2 below safmin / eps: the squares have underflowed (or are about to) and beta = sqrt(.) would be 0 or garbage -- tau = 0 / 0
+    // -> NaN in every later column.  It happens for real: inside a cluster of m nearly equal eigenvalues the subdiagonals of the reduction decay
+    // like (gap)^k (36 eigenvalues 3e-9 apart: 1e-153 after 18 columns; found by the round-6 fallback test).  LAPACK's zlarfg rescales there;
+    // such a column is zero to 1e-146 of anything representable next to it, so it is treated AS zero: H = I, beta = 0, nothing below.
+    const bool vanishing = !(norm2(alpha) + xn2 >= eps_of<T>::safmin / eps_of<T>::value);
+    if (vanishing || (xn2 == T(0) && alpha.y == T(0))) {
         tau_c = cx<T>(T(0), T(0));
         scale = cx<T>(T(0), T(0));
-        beta = alpha.x;
+        beta = vanishing ? T(0) : alpha.x;
     } else {
         const T nrm = sqrt(norm2(alpha) + xn2);
         beta = (alpha.x >= T(0)) ? -nrm : nrm;

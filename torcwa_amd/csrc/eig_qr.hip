@@ -90,12 +90,29 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     if (ag2 == T(0)) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }
     if (af2 == T(0)) { const T ig = (sizeof(T) == 8) ? (T)fast_rsqrt((double)ag2) : (T)fast_rsqrt_f64arg((double)ag2); R.c = T(0); R.s = ig * conj(g); R.r = cx<T>(ag2 * ig, T(0)); return R; }
     const T n2 = af2 + ag2;
-    T tu;                                          // 1 / (|f| d)
-    if (sizeof(T) == 8) {
-        tu = (T)fast_rsqrt((double)(af2 * n2));    // one rsqrt on the critical path (fp64 range: |f|^2 d^2 cannot under/overflow here)
-    } else {
-        tu = (T)fast_rsqrt_f64arg((double)af2 * (double)n2);      // fp32: the product is formed in fp64 (it could underflow in fp32)
+    // 1 / (|f| d) from ONE rsqrt of |f|^2 d^2, the product formed in fp64 (in fp32 it could underflow).  Outside a safe range of the product
+    // -- the result would overflow the working precision, or the product itself left the fp64 range -- both inputs are rescaled by a power of
+    // two (exact) first.  Rare but real: inside a large cluster of (nearly) equal eigenvalues -- 36 of them 3e-9 apart -- the AED's reordering
+    // meets |f| ~ 1e-100 next to |g| ~ 1e-60 (fp32: 1e-25 / 1e-15); the product underflowed, rsqrt(0) = inf, and the NaN spread over the whole
+    // matrix with info = n (rounds 1 - 5; found in round 6 through the fp64 fallback of the mixed route).
+    const double prod = (double)af2 * (double)n2;
+    const double plo = sizeof(T) == 8 ? 1e-290 : 1e-60, phi = sizeof(T) == 8 ? 1e290 : 1e60;
+    if (!(prod >= plo && prod <= phi)) {
+        const T big = fmax(fmax(fabs(f.x), fabs(f.y)), fmax(fabs(g.x), fabs(g.y)));
+        if (!(big < std::numeric_limits<T>::infinity())) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }       // non-finite input: left to the callers' checks
+        int ex;
+        (void)frexp((double)big, &ex);
+        const T sc = (T)ldexp(1.0, -ex), isc = (T)ldexp(1.0, ex);
+        const cx<T> fs = sc * f, gs = sc * g;
+        const T a2 = norm2(fs), g2 = norm2(gs), m2 = a2 + g2;
+        if (a2 == T(0)) { const T ng = sqrt(g2); R.c = T(0); R.s = (T(1) / ng) * conj(gs); R.r = cx<T>(ng * isc, T(0)); return R; }
+        const T t2 = T(1) / sqrt(a2 * m2);
+        R.c = a2 * t2;
+        R.s = t2 * (fs * conj(gs));
+        R.r = ((m2 * t2) * isc) * fs;
+        return R;
     }
+    const T tu = sizeof(T) == 8 ? (T)fast_rsqrt(prod) : (T)fast_rsqrt_f64arg(prod);
     R.c = af2 * tu;                                // |f| / d
     R.s = tu * (f * conj(g));                      // (f/|f|) conj(g) / d
     R.r = (n2 * tu) * f;                           // (f/|f|) d
