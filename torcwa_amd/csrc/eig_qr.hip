@@ -97,7 +97,12 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
     // matrix with info = n (rounds 1 - 5; found in round 6 through the fp64 fallback of the mixed route).
     const double prod = (double)af2 * (double)n2;
     const double plo = sizeof(T) == 8 ? 1e-290 : 1e-60, phi = sizeof(T) == 8 ? 1e290 : 1e60;
-    if (!(prod >= plo && prod <= phi)) {
+    const bool unsafe = !(prod >= plo && prod <= phi);              // (decided beside the rsqrt chain; the branch sits behind the fast formulas)
+    const T tu = sizeof(T) == 8 ? (T)fast_rsqrt(prod) : (T)fast_rsqrt_f64arg(prod);
+    R.c = af2 * tu;                                // |f| / d
+    R.s = tu * (f * conj(g));                      // (f/|f|) conj(g) / d
+    R.r = (n2 * tu) * f;                           // (f/|f|) d
+    if (__builtin_expect(unsafe, 0)) {
         const T big = fmax(fmax(fabs(f.x), fabs(f.y)), fmax(fabs(g.x), fabs(g.y)));
         if (!(big < std::numeric_limits<T>::infinity())) { R.c = T(1); R.s = cx<T>(T(0), T(0)); R.r = f; return R; }       // non-finite input: left to the callers' checks
         int ex;
@@ -110,12 +115,7 @@ __device__ __forceinline__ Rot<T> rotg_fast(cx<T> f, cx<T> g) {
         R.c = a2 * t2;
         R.s = t2 * (fs * conj(gs));
         R.r = ((m2 * t2) * isc) * fs;
-        return R;
     }
-    const T tu = sizeof(T) == 8 ? (T)fast_rsqrt(prod) : (T)fast_rsqrt_f64arg(prod);
-    R.c = af2 * tu;                                // |f| / d
-    R.s = tu * (f * conj(g));                      // (f/|f|) conj(g) / d
-    R.r = (n2 * tu) * f;                           // (f/|f|) d
     return R;
 }
 

@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include <cstdlib>
 #include "prof.hpp"
+#include <mutex>
 #include <string>
 
 namespace trx {
@@ -100,6 +101,145 @@ __global__ __launch_bounds__(512) void lu_panel_kernel(cx<T>* __restrict__ Aall,
     }
 }
 
+// ---- one-workgroup panel with LDS-resident sub-blocks ----------------------------------------------------------------------------
+// lu_panel_kernel walks the panel once per column from L2: a pivot search pass and a rank-1 pass, each a chain of L2 round trips of ONE
+// workgroup (14 us per column, 440 us per 32-column panel at n = 1922 -- 140 ms of a 128-point step over its LU factorisations).  Here the
+// panel is cut into sub-blocks of PSB columns; the (rows x PSB) sub-block is loaded into LDS ONCE, its PSB columns are factored there (pivot
+// search, row swaps, rank-1 updates: LDS round trips and barriers only; the swaps reach the other columns of the panel in global memory), the
+// multipliers are scaled in LDS, the sub-block goes back, and the rest of the panel receives the sub-block's contribution in ONE rank-PSB pass
+// with the multipliers still in LDS.  Same pivots, same arithmetic up to the order of the updates.  Used while rows x PSB fits the LDS budget.
+constexpr int PSB = 8;
+constexpr int PLT = 512;
+template <class T>
+__global__ __launch_bounds__(PLT) void lu_panel_lds_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb,
+                                                            int* __restrict__ piv_all, int* __restrict__ info_all) {
+    TRX_DYN_SMEM(smem);
+    constexpr int SLD = PSB + 1;                                  // row stride of the LDS sub-block (elements)
+    cx<T>* S = reinterpret_cast<cx<T>*>(smem);                    // [rows][SLD]
+    __shared__ cx<T> Ub[PSB][NB];                                 // U rows of the sub-block in the rest columns
+    __shared__ cx<T> rinv[NB];
+    __shared__ T red_v[PLT / 64];
+    __shared__ int red_i[PLT / 64];
+    __shared__ int s_piv;
+    const int b = blockIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    int* piv = piv_all + (long)b * n;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    for (int s0 = 0; s0 < jb; s0 += PSB) {
+        const int s1 = s0 + PSB < jb ? s0 + PSB : jb, ks = s1 - s0;
+        const int rtop = k0 + s0, m = n - rtop;                   // rows of this sub-block: rtop .. n - 1
+        // 1. sub-block -> LDS
+        for (int e = t; e < m * PSB; e += PLT) {
+            const int i = e / PSB, c = e - i * PSB;
+            if (c < ks) S[i * SLD + c] = A[(long)(rtop + i) * lda + k0 + s0 + c];
+        }
+        __syncthreads();
+        for (int j = s0; j < s1; ++j) {
+            const int jl = j - s0, col = k0 + j, il = j - s0;     // column inside the sub-block; its diagonal row inside S is il
+            // 2. pivot search over S[il.., jl] (LAPACK i?amax convention: max |re| + |im|, first occurrence)
+            T best = T(-1);
+            int bi = col;
+            for (int i = il + t; i < m; i += PLT) {
+                const T v = abs1(S[i * SLD + jl]);
+                if (v > best) { best = v; bi = rtop + i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const T ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) { red_v[wid] = best; red_i[wid] = bi; }
+            __syncthreads();
+            if (t == 0) {
+                T bv = red_v[0];
+                int bidx = red_i[0];
+                for (int w = 1; w < PLT / 64; ++w)
+                    if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bidx)) { bv = red_v[w]; bidx = red_i[w]; }
+                s_piv = bidx;
+                piv[col] = bidx;
+                if (!(bv > T(0)) && info_all[b] == 0) info_all[b] = col + 1;
+            }
+            __syncthreads();
+            const int p = s_piv;
+            // 3. swap rows col <-> p: inside the sub-block in LDS, in the other columns of the panel in global memory
+            if (p != col) {
+                if (t < ks) {
+                    const cx<T> a = S[il * SLD + t], c = S[(p - rtop) * SLD + t];
+                    S[il * SLD + t] = c; S[(p - rtop) * SLD + t] = a;
+                } else if (t >= 64 && t < 64 + jb) {
+                    const int c = t - 64;
+                    if (c < s0 || c >= s1) {
+                        const cx<T> a = A[(long)col * lda + k0 + c], v = A[(long)p * lda + k0 + c];
+                        A[(long)p * lda + k0 + c] = a; A[(long)col * lda + k0 + c] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            const cx<T> pv = S[il * SLD + jl];
+            const cx<T> ri = (pv.x != T(0) || pv.y != T(0)) ? crecip(pv) : cx<T>(T(0), T(0));
+            if (t == 0) rinv[j] = ri;
+            // 4. rank-1 update of the remaining columns of the sub-block (multipliers unscaled until the sub-block is done)
+            const int ncol = s1 - j - 1;
+            if (ncol > 0) {
+                for (int e = t; e < (m - il - 1) * ncol; e += PLT) {
+                    const int i = il + 1 + e / ncol, c = jl + 1 + e % ncol;
+                    S[i * SLD + c] -= (S[i * SLD + jl] * ri) * S[il * SLD + c];
+                }
+            }
+            __syncthreads();
+        }
+        // 5. scale the multipliers in LDS and write the sub-block back
+        for (int e = t; e < m * PSB; e += PLT) {
+            const int i = e / PSB, c = e - i * PSB;
+            if (c < ks) {
+                cx<T> v = S[i * SLD + c];
+                if (i > c) { v = v * rinv[s0 + c]; S[i * SLD + c] = v; }
+                A[(long)(rtop + i) * lda + k0 + s0 + c] = v;
+            }
+        }
+        __syncthreads();
+        if (s1 < jb) {
+            // 6. U rows of the sub-block in the rest columns: row k gets the rows above it (unit lower triangle of the scaled multipliers)
+            if (t < jb - s1) {
+                const int c = s1 + t;
+                for (int k = 0; k < ks; ++k) {
+                    cx<T> v = A[(long)(rtop + k) * lda + k0 + c];
+                    for (int kk = 0; kk < k; ++kk) v -= S[k * SLD + kk] * Ub[kk][c];
+                    Ub[k][c] = v;
+                    A[(long)(rtop + k) * lda + k0 + c] = v;
+                }
+            }
+            __syncthreads();
+            // 7. ... and the rows below in ONE pass: a[i][c] -= sum_k l[i][k] U[k][c]
+            const int nrest = jb - s1;
+            for (int e = t; e < (m - ks) * nrest; e += PLT) {
+                const int i = ks + e / nrest, c = s1 + e % nrest;
+                cx<T>* a = A + (long)(rtop + i) * lda + k0 + c;
+                cx<T> v = *a;
+#pragma unroll
+                for (int k = 0; k < PSB; ++k) if (k < ks) v -= S[i * SLD + k] * Ub[k][c];
+                *a = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// opt-in to the large dynamic LDS of lu_panel_lds_kernel: once per device and dtype, a failure is remembered (the old kernel then serves)
+constexpr size_t PANEL_LDS_MAX = 150 * 1024;
+template <class T>
+static bool panel_lds_ready() {
+    static std::mutex mu;
+    static int state[64];               // 0 = not yet set, 1 = ok, 2 = failed
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    int& st = state[dev & 63];
+    if (st == 0) st = set_max_dyn_smem((const void*)lu_panel_lds_kernel<T>, PANEL_LDS_MAX) ? 2 : 1;
+    return st == 1;
+}
+
 // ---- row-split panel for a FEW LARGE matrices ---------------------------------------------------------------------------------
 // One workgroup per matrix streams the whole (n-k0) x jb panel through one CU jb times: 1.35 ms per panel at n = 5202, a quarter of
 // the forward + adjoint step of a single [25,25] solve.  With few matrices the panel is instead cut into row blocks, W workgroups
@@ -121,6 +261,7 @@ __global__ __launch_bounds__(512) void lu_panel_kernel(cx<T>* __restrict__ Aall,
 // the split path is used while that tail is long enough and the panel tall enough (rows >= lu_split rows, default 1024).
 constexpr int LSW_MAX = 64;             // workgroups per matrix
 constexpr int LST = 256;                // threads per workgroup
+constexpr int LSB = 8;                  // columns of a sub-block of the panel (the rank-1 updates stay inside it; the rest of the panel is updated per sub-block)
 
 template <class T>
 __device__ __forceinline__ void lu_split_rows(int n, int k0, int W, int w, int& r0, int& r1) {
@@ -170,7 +311,7 @@ __global__ __launch_bounds__(LST) void lu_split_cand_kernel(const cx<T>* __restr
 
 template <class T>
 __global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int j, int W,
-                                                            int* __restrict__ piv_all, int* __restrict__ info_all) {
+                                                            int* __restrict__ piv_all, int* __restrict__ info_all, int cend) {
     __shared__ cx<T> prow[NB];
     __shared__ int chosen[NB];
     __shared__ T red_v[LST / 64];
@@ -221,48 +362,142 @@ __global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ A
     const cx<T> ri = (pv.x != T(0) || pv.y != T(0)) ? crecip(pv) : cx<T>(T(0), T(0));
     int r0, r1;
     lu_split_rows<T>(n, k0, W, w, r0, r1);
-    // 16 lanes per row (2 columns each), 16 rows per pass, LUR passes in flight: the loads of LUR x 16 rows are issued before the first
-    // result is needed (one pass at a time the loop was a chain of ~15 dependent L2 round trips per column launch: 52 us per launch at
-    // batch 128 for 1.2 TB/s of traffic -- latency, not bandwidth)
-    const int cpart = t & 15, rpart = t >> 4;
+    // Columns j + 1 .. cend - 1 only: the rest of the panel gets this column's contribution later, eight columns at a time
+    // (lu_split_sub_kernel).  8 lanes per row (one column each), 32 rows per pass, LUR passes in flight: the loads of LUR x 32 rows are
+    // issued before the first result is needed (one pass at a time the loop was a chain of dependent L2 round trips).
+    const int cpart = t & (LSB - 1), rpart = t / LSB;
     T best = T(-1);
     int bi = n;
     constexpr int LUR = 4;
-    static_assert(NB <= 32, "two columns per lane cover a panel");
-    const int c1 = j + 1 + cpart, c2 = c1 + 16;
-    const cx<T> u1 = c1 < jb ? prow[c1] : cx<T>(T(0), T(0)), u2 = c2 < jb ? prow[c2] : cx<T>(T(0), T(0));
-    for (int rb = r0 + rpart; rb < r1; rb += LUR * (LST / 16)) {
-        cx<T> lv[LUR], a1[LUR], a2[LUR];
+    const int c1 = j + 1 + cpart;
+    const bool c1on = c1 < cend;
+    const cx<T> u1 = c1on ? prow[c1] : cx<T>(T(0), T(0));
+    for (int rb = r0 + rpart; rb < r1; rb += LUR * (LST / LSB)) {
+        cx<T> lv[LUR], a1[LUR];
         bool on[LUR];
 #pragma unroll
         for (int u = 0; u < LUR; ++u) {
-            const int r = rb + u * (LST / 16);
+            const int r = rb + u * (LST / LSB);
             bool done = r >= r1;
             for (int q = 0; q <= j; ++q) done |= (chosen[q] == r);
             on[u] = !done;
             const cx<T>* row = A + (long)(done ? r0 : r) * lda + k0;          // (a valid address for the rows that sit out)
             lv[u] = row[j];
-            a1[u] = row[c1 < jb ? c1 : j];
-            a2[u] = row[c2 < jb ? c2 : j];
+            a1[u] = row[c1on ? c1 : j];
         }
 #pragma unroll
         for (int u = 0; u < LUR; ++u) {
-            if (!on[u]) continue;
-            const int r = rb + u * (LST / 16);
+            if (!on[u] || !c1on) continue;
+            const int r = rb + u * (LST / LSB);
             cx<T>* row = A + (long)r * lda + k0;
             const cx<T> l = lv[u] * ri;             // the multiplier itself stays unscaled in memory until lu_split_scale_kernel
-            if (c1 < jb) {
-                const cx<T> v = a1[u] - l * u1;
-                row[c1] = v;
-                if (cpart == 0) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
-            }
-            if (c2 < jb) row[c2] = a2[u] - l * u2;
+            const cx<T> v = a1[u] - l * u1;
+            row[c1] = v;
+            if (cpart == 0) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
         }
     }
-    if (j + 1 < jb) {
+    if (j + 1 < cend) {                              // (at the end of a sub-block the candidates of the next column come from lu_split_sub_kernel)
         lu_best_reduce<T>(best, bi, red_v, red_i);
         if (t == 0) cand_next[w] = bi;
     }
+}
+
+// U rows of the sub-block [s0, s1) in the panel columns [s1, jb), into LDS: U[k][c] = a[p_k][c] - sum_{s0 <= k' < k} l[p_k][k'] U[k'][c] with the
+// (unscaled) multipliers a[p_k][k'] / u_k'k' -- the frozen pivot rows have not seen each other yet in these columns.  One thread per column.
+template <class T>
+__device__ __forceinline__ void lu_split_ublock(const cx<T>* __restrict__ A, int lda, int k0, int jb, int s0, int s1, const int* chosen, const cx<T>* rinv,
+                                                cx<T> (*Ub)[NB]) {
+    const int t = threadIdx.x;
+    const int c = s1 + t;
+    if (c < jb) {
+        for (int k = s0; k < s1; ++k) {
+            const cx<T>* row = A + (long)chosen[k] * lda + k0;
+            cx<T> v = row[c];
+            for (int kk = s0; kk < k; ++kk) v -= (row[kk] * rinv[kk]) * Ub[kk - s0][c];
+            Ub[k - s0][c] = v;
+        }
+    }
+}
+
+// The sub-block [s0, s1) is factored: its contribution to the columns [s1, jb) of the panel in ONE pass (rank s1 - s0) over the rows that are
+// not pivots yet, and the candidates of column s1.  Pivot rows are only read.
+template <class T>
+__global__ __launch_bounds__(LST) void lu_split_sub_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int s0, int s1, int W,
+                                                            int* __restrict__ piv_all) {
+    __shared__ cx<T> Ub[LSB][NB];
+    __shared__ cx<T> rinv[NB];
+    __shared__ int chosen[NB];
+    __shared__ T red_v[LST / 64];
+    __shared__ int red_i[LST / 64];
+    const int b = blockIdx.y, w = blockIdx.x, t = threadIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    int* piv = piv_all + (long)b * n;
+    int* cand_next = piv + k0 + jb + (s1 & 1) * W;
+    if (t < s1) chosen[t] = piv[k0 + t];
+    __syncthreads();
+    if (t >= s0 && t < s1) {
+        const int p = chosen[t];
+        cx<T> d(T(0), T(0));
+        if (p < n) d = A[(long)p * lda + k0 + t];
+        rinv[t] = (d.x != T(0) || d.y != T(0)) ? crecip(d) : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    lu_split_ublock<T>(A, lda, k0, jb, s0, s1, chosen, rinv, Ub);
+    __syncthreads();
+    int r0, r1;
+    lu_split_rows<T>(n, k0, W, w, r0, r1);
+    // 8 lanes per row, columns s1 + cpart, + 8, + 16; 32 rows per pass
+    const int cpart = t & (LSB - 1), rpart = t / LSB;
+    const int ks = s1 - s0;
+    T best = T(-1);
+    int bi = n;
+    for (int r = r0 + rpart; r < r1; r += LST / LSB) {
+        bool done = false;
+        for (int q = 0; q < s1; ++q) done |= (chosen[q] == r);
+        if (done) continue;
+        cx<T>* row = A + (long)r * lda + k0;
+        cx<T> l[LSB];
+#pragma unroll
+        for (int k = 0; k < LSB; ++k) l[k] = k < ks ? row[s0 + k] * rinv[s0 + k] : cx<T>(T(0), T(0));
+#pragma unroll
+        for (int cc = 0; cc < NB / LSB; ++cc) {
+            const int c = s1 + cpart + LSB * cc;
+            if (c >= jb) continue;
+            cx<T> v = row[c];
+#pragma unroll
+            for (int k = 0; k < LSB; ++k) v -= l[k] * Ub[k][c];
+            row[c] = v;
+            if (c == s1) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
+        }
+    }
+    lu_best_reduce<T>(best, bi, red_v, red_i);
+    if (t == 0) cand_next[w] = bi;
+}
+
+// ... and the U rows themselves: the sub-block's pivot rows in the columns [s1, jb) (a launch of its own: lu_split_sub_kernel reads them)
+template <class T>
+__global__ __launch_bounds__(64) void lu_split_urow_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb, int s0, int s1,
+                                                            const int* __restrict__ piv_all) {
+    __shared__ cx<T> Ub[LSB][NB];
+    __shared__ cx<T> rinv[NB];
+    __shared__ int chosen[NB];
+    const int b = blockIdx.x, t = threadIdx.x;
+    cx<T>* A = Aall + (long)b * sA;
+    const int* piv = piv_all + (long)b * n;
+    if (t < s1) chosen[t] = piv[k0 + t];
+    __syncthreads();
+    if (t >= s0 && t < s1) {
+        const int p = chosen[t];
+        cx<T> d(T(0), T(0));
+        if (p < n) d = A[(long)p * lda + k0 + t];
+        rinv[t] = (d.x != T(0) || d.y != T(0)) ? crecip(d) : cx<T>(T(0), T(0));
+    }
+    __syncthreads();
+    lu_split_ublock<T>(A, lda, k0, jb, s0, s1, chosen, rinv, Ub);
+    __syncthreads();
+    const int c = s1 + t;
+    if (c < jb)
+        for (int k = s0; k < s1; ++k) A[(long)chosen[k] * lda + k0 + c] = Ub[k - s0][c];
 }
 
 // L[r, j] = a[r, j] / u_jj for every column j at which row r was not a pivot yet (rows still at their original positions)
@@ -484,13 +719,24 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
         if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
             ProfScope prof(PROF_LU_PANEL, s, 0, 0);
             TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
-            for (int j = 0; j < jb; ++j)
-                TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info);
+            for (int s0 = 0; s0 < jb; s0 += LSB) {
+                const int s1 = s0 + LSB < jb ? s0 + LSB : jb;
+                for (int j = s0; j < s1; ++j)
+                    TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info, s1);
+                if (s1 < jb) {
+                    TRX_LAUNCH((lu_split_sub_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, s0, s1, W, piv);
+                    TRX_LAUNCH((lu_split_urow_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, s0, s1, (const int*)piv);
+                }
+            }
             TRX_LAUNCH((lu_split_scale_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, W, (const int*)piv);
             TRX_LAUNCH((lu_split_final_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, piv);
         } else {
             ProfScope prof(PROF_LU_PANEL, s, 0, 0);
-            TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
+            const size_t sm_p = sizeof(cx<T>) * (size_t)(n - c0) * (PSB + 1);
+            if (sm_p <= PANEL_LDS_MAX && panel_lds_ready<T>())
+                TRX_LAUNCH((lu_panel_lds_kernel<T>), dim3(batch), dim3(PLT), sm_p, s, A, lda, sA, n, c0, jb, piv, info);
+            else
+                TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
         }
         // the panel's interchanges on the OTHER columns of this outer block (left: factors of the block's earlier panels; right: columns
         // of the block still to be factored); the columns outside the block follow when the block is done
