@@ -394,6 +394,7 @@ __global__ __launch_bounds__(LST) void lu_split_col_kernel(cx<T>* __restrict__ A
             const cx<T> v = a1[u] - l * u1;
             row[c1] = v;
             if (cpart == 0) { const T a = abs1(v); if (a > best) { best = a; bi = r; } }
+            for (int c = c1 + LSB; c < cend; c += LSB) row[c] -= l * prow[c];        // (only with knob lu_sub = 1: the whole panel column by column)
         }
     }
     if (j + 1 < cend) {                              // (at the end of a sub-block the candidates of the next column come from lu_split_sub_kernel)
@@ -682,6 +683,8 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
+static int lu_sub_env() { const char* e = getenv("TRX_LU_SUB"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 1) ? v : 0; }
+static int g_lu_sub = lu_sub_env();       // trx_tuning("lu_sub", v): 0 = panels in sub-blocks of 8 columns (default), 1 = column by column as in rounds 1 - 5
 static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
@@ -690,6 +693,7 @@ int lu_set_knob(const char* key, int value) {
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
     if (k == "lu_split") g_lu_split_rows = value;
     else if (k == "lu_split_batch") g_lu_split_batch = value;
+    else if (k == "lu_sub") { if (value > 1) return TRX_ERR_ARG; g_lu_sub = value; }
     else return TRX_ERR_ARG;
     return TRX_OK;
 }
@@ -719,8 +723,9 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
         if (batch <= split_batch && g_lu_split_rows != 1 && rows >= split_min && W >= 2 && n - c0 - jb >= 2 * W) {
             ProfScope prof(PROF_LU_PANEL, s, 0, 0);
             TRX_LAUNCH((lu_split_cand_kernel<T>), dim3(W, batch), dim3(LST), 0, s, (const cx<T>*)A, lda, sA, n, c0, jb, W, piv);
-            for (int s0 = 0; s0 < jb; s0 += LSB) {
-                const int s1 = s0 + LSB < jb ? s0 + LSB : jb;
+            const int lsb = g_lu_sub == 1 ? jb : LSB;
+            for (int s0 = 0; s0 < jb; s0 += lsb) {
+                const int s1 = s0 + lsb < jb ? s0 + lsb : jb;
                 for (int j = s0; j < s1; ++j)
                     TRX_LAUNCH((lu_split_col_kernel<T>), dim3(W, batch), dim3(LST), 0, s, A, lda, sA, n, c0, jb, j, W, piv, info, s1);
                 if (s1 < jb) {
@@ -733,7 +738,7 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
         } else {
             ProfScope prof(PROF_LU_PANEL, s, 0, 0);
             const size_t sm_p = sizeof(cx<T>) * (size_t)(n - c0) * (PSB + 1);
-            if (sm_p <= PANEL_LDS_MAX && panel_lds_ready<T>())
+            if (g_lu_sub != 1 && sm_p <= PANEL_LDS_MAX && panel_lds_ready<T>())
                 TRX_LAUNCH((lu_panel_lds_kernel<T>), dim3(batch), dim3(PLT), sm_p, s, A, lda, sA, n, c0, jb, piv, info);
             else
                 TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
