@@ -45,22 +45,24 @@ def test_gemm(backend, dtype, tol, opA, opB, m, n, k):
     (2, 0, 330, 259, 131, 1.0),                     # A conjugate-transposed; 17 slabs with a K tail of 3
     (1, 1, 321, 270, 70, 0.0),
 ])
-def test_gemm_large_tile(backend, opA, opB, m, n, k, beta):
-    """gemm_big.hip (128 x 96 tile on 8 waves, direct-to-LDS ring): against numpy, with the thin-remainder peel of gemm.hip in play."""
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-12), (np.complex64, 2e-5)])
+def test_gemm_large_tile(backend, opA, opB, m, n, k, beta, dtype, tol):
+    """The large tiles against numpy, with the thin-remainder peel of gemm.hip in play: gemm_big.hip (fp64: 128 x 96 on 8 waves, direct-to-LDS
+    ring) and gemm_f32_big_kernel (fp32: 128 x 128, a wave owns 64 x 64)."""
     be = get_backend(backend)
     batch = 2
-    dtype = np.complex128
     A = crand((batch, m, k) if opA == 0 else (batch, k, m), dtype)
     B = crand((batch, k, n) if opB == 0 else (batch, n, k), dtype)
     C0 = crand((batch, m, n), dtype)
     al, bt = np.array([0.7 - 0.2j], dtype=dtype), np.array([beta * (-0.3 + 0.5j)], dtype=dtype)
     dA, dB, dC = be.dev(A), be.dev(B), be.dev(C0)
-    rc = be.lib.gemm(1, opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
+    rc = be.lib.gemm(dtcode(dtype), opA, opB, m, n, k, al.ctypes.data, be.ptr(dA), A.shape[2], A.shape[1] * A.shape[2],
                      be.ptr(dB), B.shape[2], B.shape[1] * B.shape[2], bt.ctypes.data, be.ptr(dC), n, m * n, batch, be.stream)
     assert rc == 0
     f = {0: lambda x: x, 1: lambda x: x.transpose(0, 2, 1), 2: lambda x: x.conj().transpose(0, 2, 1)}
-    ref = al[0] * (f[opA](A) @ f[opB](B)) + bt[0] * C0
-    assert np.abs(be.host(dC) - ref).max() / np.abs(ref).max() < 1e-12
+    A128, B128 = A.astype(np.complex128), B.astype(np.complex128)
+    ref = al[0].astype(np.complex128) * (f[opA](A128) @ f[opB](B128)) + bt[0].astype(np.complex128) * C0.astype(np.complex128)
+    assert np.abs(be.host(dC) - ref).max() / np.abs(ref).max() < tol
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
