@@ -172,134 +172,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     }
 }
 
-// ---- 128 x 128 tile for large fp32 products ------------------------------------------------------------------------------------------------
-// The 64 x 64 tile moves 16 KB of operands per 0.5 MFLOP of a K slab: 32 flop/B, i.e. 4.9 TB/s out of L2 at the fp32 matrix peak -- it ran at
-// 0.53 of that peak on the large products of the fp32 stages (LU and solves of the refinement's preconditioner, eigenvector back-transform).
-// Same kernel shape with four times the block: 4 waves as 2 x 2, a wave owns 64 x 64 (4 x 4 MFMA tiles, 128 accumulator registers), BK = 16,
-// 64 flop/B, one fragment read per four MFMAs.  fp32 only (the fp64 products have gemm_big.hip); ragged edges by clamped loads and guarded
-// stores, thin remainders peeled by the caller as for the fp64 large tile.
-template <int OPA, int OPB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(int m, int n, int k, cx<float> alpha, const cx<float>* __restrict__ A, int lda, long sA,
-                                                              const cx<float>* __restrict__ B, int ldb, long sB, cx<float> beta, cx<float>* __restrict__ C,
-                                                              int ldc, long sC, int b_upper) {
-    typedef float T;
-    constexpr int BK = 16, LDK = BK + 2, MT = 4, NT = 4, BM = 128, BN = 128;
-    constexpr int LDMA = ldm_of(BM), LDMB = ldm_of(BN);
-    constexpr int RA = BM * BK / 256, RB = BN * BK / 256;
-    __shared__ T Ar[plane_of(BM, OPA == TRX_OP_N, BK)];
-    __shared__ T Ai[plane_of(BM, OPA == TRX_OP_N, BK)];
-    __shared__ T Br[plane_of(BN, OPB != TRX_OP_N, BK)];
-    __shared__ T Bi[plane_of(BN, OPB != TRX_OP_N, BK)];
-    const int b = blockIdx.z;
-    A += (long)b * sA;
-    B += (long)b * sB;
-    C += (long)b * sC;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (m0 >= m || n0 >= n) return;
-    if (b_upper && n0 + BN < k) k = n0 + BN;
-    const int t = threadIdx.x;
-    constexpr bool A_KC = (OPA == TRX_OP_N), B_KC = (OPB != TRX_OP_N);
-    constexpr int sAr = A_KC ? LDK : 1, sAk = A_KC ? 1 : LDMA;
-    constexpr int sBc = B_KC ? LDK : 1, sBk = B_KC ? 1 : LDMB;
-    cx<T> ra[RA], rb[RB];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int e = t + 256 * r;
-            const int row = A_KC ? (e / BK) : (e % BM), kk = A_KC ? (e % BK) : (e / BM);
-            const int gr = (m0 + row < m) ? m0 + row : m - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            ra[r] = (OPA == TRX_OP_N) ? A[(unsigned)(gr * lda + gk)] : A[(unsigned)(gk * lda + gr)];
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int e = t + 256 * r;
-            const int col = B_KC ? (e / BK) : (e % BN), kk = B_KC ? (e % BK) : (e / BN);
-            const int gc = (n0 + col < n) ? n0 + col : n - 1, gk = (k0 + kk < k) ? k0 + kk : k - 1;
-            rb[r] = (OPB == TRX_OP_N) ? B[(unsigned)(gk * ldb + gc)] : B[(unsigned)(gc * ldb + gk)];
-        }
-    };
-    auto store_tiles = [&](int k0) {
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int e = t + 256 * r;
-            const int row = A_KC ? (e / BK) : (e % BM), ka = A_KC ? (e % BK) : (e / BM);
-            const bool ok = (m0 + row < m) && (k0 + ka < k);
-            cx<T> v = ra[r];
-            if (OPA == TRX_OP_C) v.y = -v.y;
-            Ar[row * sAr + ka * sAk] = ok ? v.x : T(0); Ai[row * sAr + ka * sAk] = ok ? v.y : T(0);
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int e = t + 256 * r;
-            const int col = B_KC ? (e / BK) : (e % BN), kb = B_KC ? (e % BK) : (e / BN);
-            const bool ok = (n0 + col < n) && (k0 + kb < k);
-            cx<T> v = rb[r];
-            if (OPB == TRX_OP_C) v.y = -v.y;
-            Br[col * sBc + kb * sBk] = ok ? v.x : T(0); Bi[col * sBc + kb * sBk] = ok ? v.y : T(0);
-        }
-    };
-    typename Mfma<T>::acc_t accR[MT][NT], accI[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { accR[i][j][r] = T(0); accI[i][j][r] = T(0); }
-    const int wave = t >> 6, lane = t & 63;
-    const int arow0 = 16 * MT * (wave & 1), bcol0 = 16 * NT * (wave >> 1);
-    const bool has_beta = (beta.x != T(0)) || (beta.y != T(0));
-    const int col_l = lane & 15;
-    load_tiles(0);
-    for (int k0 = 0; k0 < k; k0 += BK) {
-        store_tiles(k0);
-        __syncthreads();
-        if (k0 + BK < k) load_tiles(k0 + BK);
-        __builtin_amdgcn_sched_barrier(0);          // the next slab's loads are issued ahead of this slab's MFMAs and first used after them
-        if (m0 + arow0 < m && n0 + bcol0 < n)       // (wave-uniform: a wave block entirely outside the matrix issues no MFMAs)
-            cmma_tile_strided_mt<T, MT, NT>(Ar, Ai, sAr, sAk, arow0, Br, Bi, sBk, sBc, bcol0, BK, accR, accI);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + arow0 + 16 * i + Mfma<T>::crow(lane, r);
-            if (row >= m) continue;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = n0 + bcol0 + 16 * j + col_l;
-                if (col >= n) continue;
-                cx<T> v = alpha * cx<T>(accR[i][j][r], accI[i][j][r]);
-                if (has_beta) v += beta * C[(long)row * ldc + col];
-                C[(long)row * ldc + col] = v;
-            }
-        }
-}
-
-template <int OPA>
-static int launch_f32_big_b(hipStream_t s, int opB, int batch, int m, int n, int k, cx<float> alpha, const cx<float>* A, int lda, long sA, const cx<float>* B, int ldb,
-                            long sB, cx<float> beta, cx<float>* C, int ldc, long sC, int b_upper) {
-    const dim3 grid(cdiv_i(n, 128), cdiv_i(m, 128), batch);
-    switch (opB) {
-        case TRX_OP_N: TRX_LAUNCH((gemm_f32_big_kernel<OPA, TRX_OP_N>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper); break;
-        case TRX_OP_T: TRX_LAUNCH((gemm_f32_big_kernel<OPA, TRX_OP_T>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper); break;
-        case TRX_OP_C: TRX_LAUNCH((gemm_f32_big_kernel<OPA, TRX_OP_C>), grid, dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper); break;
-        default: return TRX_ERR_ARG;
-    }
-    TRX_CHECK_LAUNCH();
-    return TRX_OK;
-}
-static int launch_f32_big(hipStream_t s, int opA, int opB, int batch, int m, int n, int k, cx<float> alpha, const cx<float>* A, int lda, long sA, const cx<float>* B, int ldb,
-                          long sB, cx<float> beta, cx<float>* C, int ldc, long sC, int b_upper) {
-    switch (opA) {
-        case TRX_OP_N: return launch_f32_big_b<TRX_OP_N>(s, opB, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
-        case TRX_OP_T: return launch_f32_big_b<TRX_OP_T>(s, opB, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
-        case TRX_OP_C: return launch_f32_big_b<TRX_OP_C>(s, opB, batch, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
-        default: return TRX_ERR_ARG;
-    }
-}
-
+// (A 128 x 128 tile for large fp32 products -- same kernel shape, a wave owning 64 x 64, 249 registers -- was measured in round 6 and removed:
+// gemm<N,N> fp32 stayed at 0.55 of the fp32 matrix peak on the refinement's LU / solve products, and the rank-32 / 64 updates of the Hessenberg
+// reduction it also caught lost parallelism: that phase went from 909 to 982 ms.  profiles/r06_ab/r6i_ninth_call.txt)
 // Large-tile fp64 kernel of gemm_big.hip (128 x 96 on 8 waves): trx_tuning("gemm_big", v) / TRX_GEMM_BIG, v = 0 automatic (= on), 4 = off (64 x 64
 // tile of this file everywhere).  Measured on MI355X at 1922^3 x 128 (profiles/r04_ab/r4_gemm_big.txt): 73.2 (off) / 85.2 TF-equivalent.
 static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 4) ? v : 0; }
@@ -386,28 +261,6 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
             if (rn) {      // right columns of the rows above
                 const cx<T>* Bc = B + (opB == TRX_OP_N ? (long)nm : (long)nm * ldb);
                 rc = launch_dispatch<T>(s, opA, opB, 1, batch, mm, rn, k, alpha, A, lda, sA, Bc, ldb, sB, beta, C + nm, ldc, sC);
-                if (rc != TRX_OK) return rc;
-            }
-            return TRX_OK;
-        }
-    }
-    if constexpr (sizeof(T) == 4) {
-        // 128 x 128 tile for large fp32 outputs (knob gemm_big = 4: off); thin remainders (at most 32 rows / columns beyond a multiple of 128:
-        // 1922 = 15 x 128 + 2) are peeled off for the flat / narrow tiles
-        if (g_gemm_big != 4 && !desc && m >= 256 && n >= 256 && k >= 32) {
-            const int rm = (m % 128) <= 32 ? m % 128 : 0, rn = (n % 128) <= 32 ? n % 128 : 0;
-            const int mm = m - rm, nm = n - rn;
-            int rc = launch_f32_big(s, opA, opB, batch, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
-            if (rc != TRX_OK) return rc;
-            if (rm) {      // bottom rows, all columns
-                const cx<T>* Arow = A + (opA == TRX_OP_N ? (long)mm * lda : (long)mm);
-                rc = launch_dispatch<T>(s, opA, opB, 2, batch, rm, n, k, alpha, Arow, lda, sA, B, ldb, sB, beta, C + (long)mm * ldc, ldc, sC, nullptr, b_upper);
-                if (rc != TRX_OK) return rc;
-            }
-            if (rn) {      // right columns of the rows above
-                const cx<T>* Bc = B + (opB == TRX_OP_N ? (long)nm : (long)nm * ldb);
-                // (b_upper: the k range of a column tile ends at its last column -- the peeled columns are the last ones, so they take the full k)
-                rc = launch_dispatch<T>(s, opA, opB, 1, batch, mm, rn, k, alpha, A, lda, sA, Bc, ldb, sB, beta, C + nm, ldc, sC, nullptr, 0);
                 if (rc != TRX_OK) return rc;
             }
             return TRX_OK;

@@ -66,43 +66,6 @@ __device__ __forceinline__ void cmma_tile_strided(const T* __restrict__ Ar, cons
     }
 }
 
-// MT x NT tiles per wave (a 16 MT x 16 NT complex block), 4M product: the MT + NT fragment pairs of a k-step are read once and feed
-// 4 MT NT MFMAs (64 for the 64 x 64 wave block of the 128 x 128 fp32 tile: one LDS read per four MFMAs instead of one per 1.6).
-template <class T, int MT, int NT>
-__device__ __forceinline__ void cmma_tile_strided_mt(const T* __restrict__ Ar, const T* __restrict__ Ai, int sAr, int sAk, int arow0,
-                                                     const T* __restrict__ Br, const T* __restrict__ Bi, int sBk, int sBc, int bcol0, int kcount,
-                                                     typename Mfma<T>::acc_t (&accR)[MT][NT], typename Mfma<T>::acc_t (&accI)[MT][NT]) {
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int aoff = (arow0 + lr) * sAr + lk * sAk;
-    const int boff = lk * sBk + (bcol0 + lr) * sBc;
-    for (int k0 = 0; k0 < kcount; k0 += 4) {
-        T ar[MT], ai[MT], br[NT], bi[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            ar[i] = Ar[aoff + k0 * sAk + 16 * i * sAr];
-            ai[i] = Ai[aoff + k0 * sAk + 16 * i * sAr];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            br[j] = Br[boff + k0 * sBk + 16 * j * sBc];
-            bi[j] = Bi[boff + k0 * sBk + 16 * j * sBc];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const T nai = -ai[i];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) accR[i][j] = Mfma<T>::mma(ar[i], br[j], accR[i][j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) accI[i][j] = Mfma<T>::mma(ar[i], bi[j], accI[i][j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) accR[i][j] = Mfma<T>::mma(nai, bi[j], accR[i][j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) accI[i][j] = Mfma<T>::mma(ai[i], br[j], accI[i][j]);
-        }
-    }
-}
-
 // Same tile with the 3M complex product (three real MFMAs per k-step instead of four):
 //   P1 += Ar Br,  P2 += Ai Bi,  P3 += (Ar + Ai)(Br + Bi);      Cr = P1 - P2,  Ci = P3 - P1 - P2   (cmma3_finish)
 // The operand sums are formed in registers (one VALU add per fragment, co-issued with the matrix pipe), so LDS traffic and
