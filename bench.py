@@ -319,8 +319,9 @@ _LATENCY_MODEL = {
     # the column (LDS tree, ~10 barriers x ~60), write reflector + T column (one more global round trip) => ~5000 cycles per column
     "hess_col_kernel": dict(unit="columns/s per matrix", cycles_min=5000.0, steps=1.0,
                             model="2 dependent global round trips (~2000 cycles each under load) + one block reduction (~10 barriers) per column = 5000 cycles"),
-    # one 32-column LU panel (lu_split_* launches, lu.hip): per column a pivot search (global column slice + two-level reduction ~2500 cycles) and a
-    # rank-1 update of the panel (one global round trip ~2000) as ONE launch (~5 us launch latency = 12000 cycles when the chain is launch-bound)
+    # one 32-column LU panel (lu.hip; since round 6 in sub-blocks of 8 columns: per column a pivot search and a rank-1 update of the sub-block --
+    # in LDS for panels of up to ~1000 rows, else one launch per column over W workgroups per matrix -- and per sub-block one rank-8 pass over the
+    # rest of the panel): pivot search ~2500 + rank-1 update ~2000 cycles per column as the issue-limited floor of a column
     "lu_panel_kernel": dict(unit="panel columns/s per matrix", cycles_min=4500.0, steps=32.0,
                             model="pivot search ~2500 + rank-1 panel update ~2000 cycles per column, 32 columns per panel (launch latency of the per-column launches NOT included in the minimum)"),
 }
@@ -330,7 +331,7 @@ _TRACE_KEYS = {"gemm<N,N>": ("gemm_big_kernel<0, 0", "gemm_mfma_kernel<double, 0
                "apply_links_kernel<0>": ("apply_links_kernel<float, 0", "apply_links_kernel<double, 0", "apply_links_kernel<float, 2", "apply_links_kernel<double, 2"),
                "apply_links_kernel<1>": ("apply_links_kernel<float, 1", "apply_links_kernel<double, 1"),
                "hess_gemv_kernel": ("hess_gemv_kernel",), "qr_prepare_kernel": ("qr_prepare_kernel",),
-               "qr_window_kernel": ("qr_window_kernel",), "hess_col_kernel": ("hess_col_kernel",), "lu_panel_kernel": ("lu_panel_kernel", "lu_split_")}
+               "qr_window_kernel": ("qr_window_kernel",), "hess_col_kernel": ("hess_col_kernel",), "lu_panel_kernel": ("lu_panel_kernel", "lu_panel_lds_kernel", "lu_split_")}
 _TAG_SOURCES = {"gemm": ("gemm.hip", "gemm_big.hip", "mfma.hpp", "common.hpp"), "apply": ("eig_qr.hip", "mfma.hpp", "common.hpp"),
                 "qr_": ("eig_qr.hip", "common.hpp"), "hess": ("eig_hess.hip", "common.hpp"), "lu_": ("lu.hip", "common.hpp")}
 # kernels of the eigensolver proper: with the mixed-precision route (libtrx default for complex128 input, n >= 256, batch >= 8) they run in fp32
