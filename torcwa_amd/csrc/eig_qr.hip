@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         const QrLink* pl = links_all + ((long)b * nslot + prev_q0) * kc;                   // (chain 0: kc == 1 in fused launches)
         const int gc = fused_catchup_strips(pl[0].e, sst.k[0], nsteps, n);                   // strips the chase workgroup catches up on itself
         left_links_strips<T>(Aall + (long)b * mstride, n, pl, kc, Ulog_all + ((long)b * nslot + prev_q0) * kc * QW * QW, prev_nq, Ur, Ui, sflag + 1,
-                             gc + 16 * fx, 1 << 30, 16 * nfar, band_on, work);
+                             gc + 16 * fx, 1 << 30, 16 * nfar, band_on, work + 7);
         return;
     }
     long long* dbg = (DBG && dbg_all && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? dbg_all : nullptr;
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         if (pl[0].kind == QRL_CHASE) {
             const int e_prev = pl[0].e;
             const int gc = fused_catchup_strips(e_prev, st.k[0], nsteps, n);
-            left_links_strips<T>(H, n, pl, kc, Ulog_all + (((long)b * nslot + prev_q0) * kc + ch) * QW * QW, prev_nq, Ur, Ui, sflag + 1, 0, gc, WTHREADS / 64, band_on, work);
+            left_links_strips<T>(H, n, pl, kc, Ulog_all + (((long)b * nslot + prev_q0) * kc + ch) * QW * QW, prev_nq, Ur, Ui, sflag + 1, 0, gc, WTHREADS / 64, band_on, work + 7);
             band_e = fused_band_end(e_prev, st.k[0], nsteps, n);
         }
     }
@@ -1653,9 +1653,10 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         hipStream_t s;
         int b0, nb;
         int* summary;          // device, 16 ints: two slots of {[0] active matrices, [1] bound of the remaining blocks, [2] flags}; [3] / [7]: work of the
-                               // per-step / the deferred updates (cumulative, in units of 4096 complex MACs); [8] chain steps of the window kernel, [9] rotations of the AED's Schur solver
+                               // per-step / the deferred updates (cumulative, in units of 4096 complex MACs); [8] chain steps of the window kernel, [9] rotations of the AED's Schur solver,
+                               // [10] left-update work done INSIDE the window launches (far workgroups + catch-up of the fused launches; same units as [3])
         bool done;
-        unsigned work[4];
+        unsigned work[5];
         int par;               // parity of the next window step (double-buffered chase positions)
         int g;                 // group index = index of its first matrix
         int issued, read;      // outer iterations queued / summaries read
@@ -1681,7 +1682,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         G.done = false;
         G.issued = 0;
         G.read = 0;
-        G.work[0] = G.work[1] = G.work[2] = G.work[3] = 0;
+        G.work[0] = G.work[1] = G.work[2] = G.work[3] = G.work[4] = 0;
         G.par = 0;
         G.g = g;
         if (!lane_checkout(dev, g > 0, G.lane)) { rc = TRX_ERR_LAUNCH; break; }
@@ -1831,13 +1832,13 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         if (gmin >= 0 && hipEventSynchronize(grp[gmin].lane.evs[grp[gmin].read & 1]) != hipSuccess) { rc = TRX_ERR_LAUNCH; break; }
     }
     (void)hipGetLastError();          // hipEventQuery leaves hipErrorNotReady as the thread's last error
-    double work[4] = {0, 0, 0, 0};
+    double work[5] = {0, 0, 0, 0, 0};
     for (int g = 0; g < nlanes; ++g) {
         Group& G = grp[g];
         if (!rc && prof_enabled() && hipMemcpyAsync(&G.work[0], G.summary + 3, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess &&
             hipMemcpyAsync(&G.work[1], G.summary + 7, sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess &&
-            hipMemcpyAsync(&G.work[2], G.summary + 8, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess) {
-            for (int i = 0; i < 4; ++i) work[i] += G.work[i];
+            hipMemcpyAsync(&G.work[2], G.summary + 8, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, G.s) == hipSuccess && hipStreamSynchronize(G.s) == hipSuccess) {
+            for (int i = 0; i < 5; ++i) work[i] += G.work[i];
         }
         if (g > 0) {
             // join: the caller's stream waits for everything queued on the group's stream; a pooled stream goes back idle
@@ -1864,7 +1865,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
         prof_add_work(PROF_QR_APPLY_LEFT, 8.0 * 4096.0 * work[0], 2.0 * sizeof(cx<T>) * 4096.0 * work[0] / QW);
         prof_add_work(PROF_QR_APPLY_RIGHT, 8.0 * 4096.0 * work[1], 2.0 * sizeof(cx<T>) * 4096.0 * work[1] / QW);
         // latency kernels: dependent steps per MATRIX (the matrices of a launch run side by side): chain steps / rotations summed over all matrices / batch
-        prof_add_work(PROF_QR_WINDOW, work[2] / batch, 0.0);
+        // (the window tag's BYTES slot carries the flops of the left updates its launches did themselves -- far workgroups and catch-up of the
+        // fused launches; the left-update tag holds only what the stand-alone launches did, so that its work and its event time match)
+        prof_add_work(PROF_QR_WINDOW, work[2] / batch, 8.0 * 4096.0 * work[4]);
         prof_add_work(PROF_QR_PREPARE, work[3] / batch, 0.0);
     }
     TRX_LAUNCH((qr_collect_info_kernel<T>), dim3(cdiv_i(batch, 64)), dim3(64), 0, s, (const QrState*)B.st, info, batch, ngroups);

@@ -761,6 +761,38 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
     return TRX_OK;
 }
 
+// Triangular solve with the diagonal block [r0, r1) of a factored matrix (UPPER: U; otherwise unit-lower L) on the rows [r0, r1) of B, in
+// place, by recursive halving down to NB-row leaves (trsm_kernel).  Same arithmetic as marching through the block leaf by leaf with a
+// rank-NB update of all rows still to come after each leaf -- what rounds 1 - 5 did -- but that form reads and writes the remaining rows of
+// B once per leaf (3.5 block heights of traffic per block; the rank-32 fp64 updates ran at the HBM roof: 247 ms of a 128-point step,
+// profiles/r05_pmc_bench.txt), where the halving form touches every row once per LEVEL (1.5 block heights) and gives the upper levels
+// K = 128 / 64 products that are bound by the matrix cores instead.
+template <class T, bool UPPER>
+static int tri_block_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int r0, int r1, cx<T>* B, int ldb, long sB, int nrhs, int batch) {
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
+    const int m = r1 - r0;
+    if (m <= 0) return TRX_OK;
+    if (m <= NB) {
+        TRX_LAUNCH((trsm_kernel<T, UPPER>), dim3(cdiv_i(nrhs, 256), batch), dim3(256), 0, s, LU + (long)r0 * lda + r0, lda, sA, m,
+                   B + (long)r0 * ldb, ldb, sB, nrhs);
+        return TRX_OK;
+    }
+    int h = NB;                                   // largest NB * 2^k below m: full blocks split 128 | 128, 64 | 64, 32 | 32
+    while (2 * h < m) h *= 2;
+    const int mid = r0 + h;
+    int rc;
+    if (!UPPER) {
+        if ((rc = tri_block_solve<T, false>(s, LU, lda, sA, r0, mid, B, ldb, sB, nrhs, batch))) return rc;
+        if ((rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, r1 - mid, nrhs, h, mone, LU + (long)mid * lda + r0, lda, sA, B + (long)r0 * ldb, ldb, sB, one,
+                          B + (long)mid * ldb, ldb, sB, batch))) return rc;
+        return tri_block_solve<T, false>(s, LU, lda, sA, mid, r1, B, ldb, sB, nrhs, batch);
+    }
+    if ((rc = tri_block_solve<T, true>(s, LU, lda, sA, mid, r1, B, ldb, sB, nrhs, batch))) return rc;
+    if ((rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, h, nrhs, r1 - mid, mone, LU + (long)r0 * lda + mid, lda, sA, B + (long)mid * ldb, ldb, sB, one,
+                      B + (long)r0 * ldb, ldb, sB, batch))) return rc;
+    return tri_block_solve<T, true>(s, LU, lda, sA, r0, mid, B, ldb, sB, nrhs, batch);
+}
+
 // U rows of the outer block [K0, Kend) for the columns [c_lo, c_hi) right of it (trsm + in-block update per panel), then the rank-kb
 // update of the rows below the block in those columns.
 template <class T>
@@ -770,16 +802,8 @@ int lu_block_update(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
     const int tcols = c_hi - c_lo, kb = Kend - K0;
     if (tcols <= 0) return TRX_OK;
     int rc;
-    for (int c0 = K0; c0 < Kend; c0 += NB) {
-        const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-        TRX_LAUNCH((trsm_kernel<T, false>), dim3(cdiv_i(tcols, 256), batch), dim3(256), 0, s, (const cx<T>*)at(c0, c0), lda, sA, jb,
-                   at(c0, c_lo), lda, sA, tcols);
-        const int rin = Kend - (c0 + jb);
-        if (rin > 0) {
-            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, tcols, jb, mone, at(c0 + jb, c0), lda, sA, at(c0, c_lo), lda, sA, one, at(c0 + jb, c_lo), lda, sA, batch);
-            if (rc) return rc;
-        }
-    }
+    rc = tri_block_solve<T, false>(s, A, lda, sA, K0, Kend, at(0, c_lo), lda, sA, tcols, batch);
+    if (rc) return rc;
     if (n - Kend > 0) {
         rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - Kend, tcols, kb, mone, at(Kend, K0), lda, sA, at(K0, c_lo), lda, sA, one, at(Kend, c_lo), lda, sA, batch);
         if (rc) return rc;
@@ -823,15 +847,8 @@ int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int*
     for (int K0 = 0; K0 < n; K0 += NBO) {            // forward: L Y = P B
         const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
         const int Kend = K0 + kb;
-        for (int c0 = K0; c0 < Kend; c0 += NB) {
-            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-            TRX_LAUNCH((trsm_kernel<T, false>), cg, dim3(256), 0, s, lu(c0, c0), lda, sA, jb, bb(c0), ldb, sB, nrhs);
-            const int rin = Kend - (c0 + jb);
-            if (rin > 0) {
-                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, nrhs, jb, mone, lu(c0 + jb, c0), lda, sA, bb(c0), ldb, sB, one, bb(c0 + jb), ldb, sB, batch);
-                if (rc) return rc;
-            }
-        }
+        rc = tri_block_solve<T, false>(s, LU, lda, sA, K0, Kend, B, ldb, sB, nrhs, batch);
+        if (rc) return rc;
         if (n - Kend > 0) {
             rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n - Kend, nrhs, kb, mone, lu(Kend, K0), lda, sA, bb(K0), ldb, sB, one, bb(Kend), ldb, sB, batch);
             if (rc) return rc;
@@ -841,16 +858,8 @@ int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int*
     for (int K0 = lastK; K0 >= 0; K0 -= NBO) {       // backward: U X = Y
         const int kb = (n - K0 < NBO) ? (n - K0) : NBO;
         const int Kend = K0 + kb;
-        const int lastc = K0 + ((kb - 1) / NB) * NB;
-        for (int c0 = lastc; c0 >= K0; c0 -= NB) {
-            const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
-            TRX_LAUNCH((trsm_kernel<T, true>), cg, dim3(256), 0, s, lu(c0, c0), lda, sA, jb, bb(c0), ldb, sB, nrhs);
-            const int rin = c0 - K0;
-            if (rin > 0) {
-                rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, rin, nrhs, jb, mone, lu(K0, c0), lda, sA, bb(c0), ldb, sB, one, bb(K0), ldb, sB, batch);
-                if (rc) return rc;
-            }
-        }
+        rc = tri_block_solve<T, true>(s, LU, lda, sA, K0, Kend, B, ldb, sB, nrhs, batch);
+        if (rc) return rc;
         if (K0 > 0) {
             rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, K0, nrhs, kb, mone, lu(0, K0), lda, sA, bb(K0), ldb, sB, one, bb(0), ldb, sB, batch);
             if (rc) return rc;
