@@ -104,6 +104,8 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       launch per super-step, the right update of H and the update of Z one launch per sweep (link log of the sweep)
  *   "qr_defer"    1 = right update of H and update of Z after every super-step instead of once per sweep (TRX_QR_DEFER)   auto: once per sweep
  *                       when the sweep has one chain; with 2-3 chains the following chain reads the rows, so it is per step
+ *   "qr_fuse"     1 = the left update of a launch's links as its own launch after every super-step, as in round 5 (TRX_QR_FUSE)
+ *                       auto: fused -- the NEXT chase launch carries far workgroups that apply it beyond the columns the chase reaches (one chain per sweep only)
  *   "slab_spw"    1, 2, 4  strips per wave of the left update (TRX_SLAB_SPW)           auto: 1
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chase unitary
  *   Eigenvector route of trx_eig
@@ -111,15 +113,20 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       eigendecomposition refined to fp64 by Newton steps (TRX_EIG_VEC)
  *                       auto: mixed precision for complex128 input of n >= 256 AND batch >= 8, else Schur vectors; trx_eig_ws_bytes depends on
  *                       this knob (per call and race-free: trx_eig_opts).  (2, inverse iteration on the Hessenberg matrix, was removed in round 5.)
- *   "eig_refine"  1-4   Newton steps of the mixed-precision route; 0 = default (2: the accuracy class of the all-fp64 pipeline; one step
- *                       leaves an eigen-residual of ~5e-12 ||A||)
+ *   "eig_refine"  1-4   Newton steps of the mixed-precision route; 0 = default (2: eigen-residual ~1e-11 ||A||, what a complex64 caller's
+ *                       1e-5 needs with five digits to spare; 3 reach the all-fp64 pipeline's 1e-13 -- torcwa_amd.Engine asks for 3 per call
+ *                       (trx_eig_opts) whenever the caller's own dtype is complex128)
  *   GEMM (trx_gemm and every product inside the library)
  *   "gemm_big"    4 = large-tile complex128 kernel (128 x 96 on 8 waves; outputs of at least 2 x 2 tiles, k >= 64) OFF: the 64 x 64 tile everywhere
  *                       (TRX_GEMM_BIG)                                                                              auto: on
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
  *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
- *   Hessenberg reduction: TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
+ *   "lu_sub"      1 = panels column by column as in rounds 1 - 5 (TRX_LU_SUB)         auto: sub-blocks of 8 columns (same pivots)
+ *   Hessenberg reduction
+ *   "hess_group"  1-4   panels whose right updates of Z and of the rows above the panel are merged into one block reflector and applied
+ *                       together (TRX_HESS_GROUP); 1 = every panel on its own as in rounds 1 - 5                      auto: 4
+ *   TRX_HESS_RPW=2 (environment only) streams two rows per wave and pass in the BLAS-2 kernel instead of four. */
 int trx_tuning(const char* key, int value);
 
 /* Adjoint of the eigendecomposition: torcwa/torch_eig.py:19-44 (`Eig.backward`, the Lorentzian-broadened formula)

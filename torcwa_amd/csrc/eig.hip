@@ -71,6 +71,7 @@ size_t eig_ws_bytes_t(int n, int batch) {
     tot += al256(e * B * EigPlan::HNB * N) * 2;                       // W1, W2
     tot += al256(e * B * N * 2 * EigPlan::HNB) * 2;                   // YV, BC
     tot += al256(e * B * EigPlan::HNB * EigPlan::HNB);                // Sm
+    tot += al256(e * B * N * EigPlan::HGK) * 3 + al256(e * B * EigPlan::HGK * EigPlan::HGK) * 2;   // Vg, Wg, W2g, Tg, Gg
     tot += al256(e * B * EigPlan::HNB) * 2;                           // tau, tvec
     tot += al256(e * B * EigPlan::QW * EigPlan::QW);                  // U (dense link)
     {   // link log of a sweep: window unitaries + link records
@@ -110,6 +111,11 @@ void eig_carve(EigBuffers<T>& Bf, void* A, void* ws, int n, int batch) {
     Bf.YV = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
     Bf.BC = (cx<T>*)take(e * B * N * 2 * EigPlan::HNB);
     Bf.Sm = (cx<T>*)take(e * B * EigPlan::HNB * EigPlan::HNB);
+    Bf.Vg = (cx<T>*)take(e * B * N * EigPlan::HGK);
+    Bf.Wg = (cx<T>*)take(e * B * N * EigPlan::HGK);
+    Bf.W2g = (cx<T>*)take(e * B * N * EigPlan::HGK);
+    Bf.Tg = (cx<T>*)take(e * B * EigPlan::HGK * EigPlan::HGK);
+    Bf.Gg = (cx<T>*)take(e * B * EigPlan::HGK * EigPlan::HGK);
     Bf.tau = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.tvec = (cx<T>*)take(e * B * EigPlan::HNB);
     Bf.U = (cx<T>*)take(e * B * EigPlan::QW * EigPlan::QW);
@@ -377,6 +383,7 @@ extern "C" int trx_tuning(const char* key, int value) {
     int rc = trx::qr_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::lu_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::eig_set_knob(key, value);
+    if (rc != TRX_OK) rc = trx::hess_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::gemm_set_knob(key, value);
     if (rc != TRX_OK) rc = trx::refine_set_knob(key, value);
     return rc;

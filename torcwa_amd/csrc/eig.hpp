@@ -6,6 +6,8 @@ namespace trx {
 
 struct EigPlan {
     static constexpr int HNB = 32;     // Hessenberg panel width
+    static constexpr int HG = 4;       // panels per group of the delayed right updates (eig_hess.hip)
+    static constexpr int HGK = HG * HNB;
     static constexpr int QW = 64;      // QR window size (rows/cols staged in LDS)
     static constexpr int QNS = 16;     // shifts (= bulges) per CHAIN, spaced 2 rows apart
     static constexpr int QKC = 3;      // bulge chains per sweep (each in its own window, at least one window apart)
@@ -50,6 +52,11 @@ struct EigBuffers {
     cx<T>* YV;     // [B,n,2*HNB]   [Y | V] operand of the fused trailing update
     cx<T>* BC;     // [B,2*HNB,n]   [Vt^H ; T^H W]
     cx<T>* Sm;     // [B,HNB,HNB]   V^H Y
+    cx<T>* Vg;     // [B,n,HGK]     reflectors of a group of HG panels side by side (delayed right updates of Z and of the rows above the group)
+    cx<T>* Wg;     // [B,n,HGK]     X Vg
+    cx<T>* W2g;    // [B,n,HGK]     X Vg Tg
+    cx<T>* Tg;     // [B,HGK,HGK]   merged triangular factor of the group
+    cx<T>* Gg;     // [B,HGK,HGK]   Vg^H Vg
     cx<T>* tau;    // [B,HNB]
     cx<T>* tvec;   // [B,HNB]  V^H v of the current panel column
     cx<T>* U;      // [B,QW,QW] unitary of the last AED window / finished small block (dense link)
@@ -105,6 +112,7 @@ template <class T> int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, 
 template <class T> int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* info);
 int qr_set_knob(const char* key, int value);
 int eig_set_knob(const char* key, int value);
+int hess_set_knob(const char* key, int value);
 template <class T> int schur_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* w, cx<T>* V);
 // V <- D V (undo of the balancing) with unit 2-norm columns
 template <class T> int finish_vectors(hipStream_t s, const EigBuffers<T>& B, int n, int batch, cx<T>* V);

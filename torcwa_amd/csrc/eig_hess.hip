@@ -269,6 +269,27 @@ __global__ __launch_bounds__(256) void conj_transpose_panel_kernel(const cx<T>* 
     BCall[(long)b * 2 * HNB * n + (long)c * n + j] = conj(Vall[((long)b * n + row0 + j) * HNB + c]);
 }
 
+
+// Delayed right updates (round 6): the reflector blocks of HG consecutive panels are kept side by side, Vg = [V_0 | V_1 | ...] (explicit zeros
+// above each panel's first row and in unused columns), with the diagonal blocks of the merged triangular factor Tg.
+template <class T>
+__global__ __launch_bounds__(256) void pack_group_kernel(const cx<T>* __restrict__ Vall, const cx<T>* __restrict__ Tall, cx<T>* __restrict__ Vg_all,
+                                                         cx<T>* __restrict__ Tg_all, int n, int g_r0, int r0, int ib, int gp) {
+    constexpr int GK = EigPlan::HGK;
+    const int b = blockIdx.y;
+    const int r = g_r0 + blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+    if (r < n) Vg_all[((long)b * n + r) * GK + gp * HNB + c] = (r >= r0 && c < ib) ? Vall[((long)b * n + r) * HNB + c] : cx<T>(T(0), T(0));
+    if (blockIdx.x == 0) {
+        cx<T>* Tg = Tg_all + (long)b * GK * GK;
+        const cx<T>* Tm = Tall + (long)b * HNB * HNB;
+        for (int i = threadIdx.x >> 5; i < HNB; i += 8) {
+            // row block gp of Tg: zero left of the diagonal block (and right of it: filled by the merge), the panel's T on the diagonal
+            for (int q = 0; q < EigPlan::HG; ++q)
+                Tg[(long)(gp * HNB + i) * GK + q * HNB + c] = (q == gp && i < ib && c < ib) ? Tm[i * HNB + c] : cx<T>(T(0), T(0));
+        }
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ X, int n) {
     cx<T>* M = X + (long)blockIdx.z * n * n;
@@ -284,6 +305,58 @@ __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ 
 static int hess_rpw(int batch) {
     static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return (x == 2 || x == 4) ? x : 0; }();
     return v ? v : (batch >= 64 ? 2 : 4);
+}
+
+// Panels per group of the delayed right updates (TRX_HESS_GROUP / trx_tuning("hess_group", g)): 0 automatic (4), 1 = every panel on its own as in
+// rounds 1 - 5.
+static int hess_group_env() { const char* e = getenv("TRX_HESS_GROUP"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= EigPlan::HG) ? v : 0; }
+static int g_hess_group = hess_group_env();
+int hess_set_knob(const char* key, int value) {
+    if (std::string(key) != "hess_group" || value < 0 || value > EigPlan::HG) return TRX_ERR_ARG;
+    g_hess_group = value;
+    return TRX_OK;
+}
+
+// The right updates of a panel's block reflector touch two regions that never feed back into the reduction: the rows of A above the panel and
+// all of Z.  Per panel they are rank-32 updates that read and write the region once each (plus one read for X V): bound by HBM, and half of
+// the traffic of the phase's block updates.  They are therefore DELAYED: the reflectors of up to HG = 4 consecutive panels are merged,
+//     (I - V_a T_a V_a^H)(I - V_b T_b V_b^H) = I - [V_a V_b] [[T_a, -T_a (V_a^H V_b) T_b], [0, T_b]] [V_a V_b]^H,
+// and applied at once as a rank-128 update: a quarter of the passes, and products the matrix cores bound.  Rows of A between the group's
+// first row g_r0 and a later panel's first row are "above" that panel only: those (at most 96) rows keep the per-panel update.
+template <class T>
+static int hess_flush_group(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int g_r0, int np) {
+    constexpr int GK = EigPlan::HGK;
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0)), zero(T(0), T(0));
+    const long nn = (long)n * n, sVg = (long)n * GK, sTg = (long)GK * GK;
+    cx<T>*Vg = B.Vg, *Tg = B.Tg, *Gg = B.Gg, *Wg = B.Wg, *W2g = B.W2g, *A = B.A, *Z = B.Z;
+    const int kk = np * HNB, nr = n - g_r0;
+    int rc;
+    if (np > 1) {
+        // G = Vg^H Vg (only the blocks above the diagonal are used), then the off-diagonal blocks of the merged T, pairs first
+        rc = gemm<T>(s, TRX_OP_C, TRX_OP_N, kk, kk, nr, one, Vg + (long)g_r0 * GK, GK, sVg, Vg + (long)g_r0 * GK, GK, sVg, zero, Gg, GK, sTg, batch); if (rc) return rc;
+        auto merge = [&](int a0, int ka, int b0, int kb) {      // Tg[a, b] = -Tg[a, a] G[a, b] Tg[b, b]   (W2g: scratch)
+            int r = gemm<T>(s, TRX_OP_N, TRX_OP_N, ka, kb, kb, one, Gg + (long)a0 * GK + b0, GK, sTg, Tg + (long)b0 * GK + b0, GK, sTg, zero, W2g, GK, sVg, batch);
+            if (r) return r;
+            return gemm<T>(s, TRX_OP_N, TRX_OP_N, ka, kb, ka, mone, Tg + (long)a0 * GK + a0, GK, sTg, W2g, GK, sVg, zero, Tg + (long)a0 * GK + b0, GK, sTg, batch);
+        };
+        rc = merge(0, HNB, HNB, HNB); if (rc) return rc;
+        if (np == 3) { rc = merge(0, 2 * HNB, 2 * HNB, HNB); if (rc) return rc; }
+        if (np == 4) {
+            rc = merge(2 * HNB, HNB, 3 * HNB, HNB); if (rc) return rc;
+            rc = merge(0, 2 * HNB, 2 * HNB, 2 * HNB); if (rc) return rc;
+        }
+    }
+    // rows of A above the group: A[0:g_r0, g_r0:n] <- A[0:g_r0, g_r0:n] (I - Vg Tg Vg^H)
+    if (g_r0 > 0) {
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, g_r0, kk, nr, one, A + g_r0, n, nn, Vg + (long)g_r0 * GK, GK, sVg, zero, Wg, GK, sVg, batch); if (rc) return rc;
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, g_r0, kk, kk, one, Wg, GK, sVg, Tg, GK, sTg, zero, W2g, GK, sVg, batch); if (rc) return rc;
+        rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, g_r0, nr, kk, mone, W2g, GK, sVg, Vg + (long)g_r0 * GK, GK, sVg, one, A + g_r0, n, nn, batch); if (rc) return rc;
+    }
+    // Z[:, g_r0:n] <- Z[:, g_r0:n] (I - Vg Tg Vg^H)
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, kk, nr, one, Z + g_r0, n, nn, Vg + (long)g_r0 * GK, GK, sVg, zero, Wg, GK, sVg, batch); if (rc) return rc;
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, kk, kk, one, Wg, GK, sVg, Tg, GK, sTg, zero, W2g, GK, sVg, batch); if (rc) return rc;
+    rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, n, nr, kk, mone, W2g, GK, sVg, Vg + (long)g_r0 * GK, GK, sVg, one, Z + g_r0, n, nn, batch); if (rc) return rc;
+    return TRX_OK;
 }
 
 // (Two to four sub-batches on side streams, half a panel out of phase -- one's block updates and reflector kernels under the other's gemv
@@ -303,6 +376,8 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     const int rpw = hess_rpw(batch);
     cx<T>* Bcol = W;            // [B, n]        next column with the pending right update applied (the GEMM scratch is free during the column loop)
     cx<T>* wpart = W2;          // [B, nwg, HNB] partial sums of V^H b, one row per workgroup of the wide launch
+    const int hg = g_hess_group ? g_hess_group : EigPlan::HG;        // panels per group of the delayed right updates (1: none delayed)
+    int g_r0 = 1, gp = 0;                                            // first row of the current group, panels it holds
     for (int p0 = 0; p0 < n - 2; p0 += HNB) {
         const int ib = (n - 2 - p0 < HNB) ? (n - 2 - p0) : HNB;
         const int r0 = p0 + 1, nr = n - r0;
@@ -330,11 +405,15 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
         }
         int rc;
         const int mt = n - p0 - ib;       // trailing columns
-        // (1) Ytop = (A[0:r0, r0:n] V[r0:n,:]) T
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, r0, ib, nr, one, A + r0, n, nn, V + (long)r0 * HNB, HNB, sV, zero, W, HNB, sW, batch); if (rc) return rc;
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, r0, ib, ib, one, W, HNB, sW, Tm, HNB, sT, zero, Y, HNB, sV, batch); if (rc) return rc;
-        // (2) A[0:r0, r0:n] -= Ytop V[r0:n,:]^H
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, r0, nr, ib, mone, Y, HNB, sV, V + (long)r0 * HNB, HNB, sV, one, A + r0, n, nn, batch); if (rc) return rc;
+        if (gp == 0) g_r0 = r0;
+        const int t0 = hg > 1 ? g_r0 : 0, tr = r0 - t0;      // rows above the panel that are updated now: all of them (hg == 1) or those inside the group
+        if (tr > 0) {
+            // (1) Ytop = (A[t0:r0, r0:n] V[r0:n,:]) T
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, tr, ib, nr, one, A + (long)t0 * n + r0, n, nn, V + (long)r0 * HNB, HNB, sV, zero, W, HNB, sW, batch); if (rc) return rc;
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, tr, ib, ib, one, W, HNB, sW, Tm, HNB, sT, zero, Y + (long)t0 * HNB, HNB, sV, batch); if (rc) return rc;
+            // (2) A[t0:r0, r0:n] -= Ytop V[r0:n,:]^H
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, tr, nr, ib, mone, Y + (long)t0 * HNB, HNB, sV, V + (long)r0 * HNB, HNB, sV, one, A + (long)t0 * n + r0, n, nn, batch); if (rc) return rc;
+        }
         if (mt > 0) {
             cx<T>* At = A + (long)r0 * n + p0 + ib;           // A[R, p0+ib:n]
             if (ib == HNB) {
@@ -360,10 +439,20 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
                 rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nr, mt, ib, mone, V + (long)r0 * HNB, HNB, sV, W2, n, sW, one, At, n, nn, batch); if (rc) return rc;
             }
         }
-        // (7-9) Z[:, R] -= ((Z[:, R] V[R,:]) T) V[R,:]^H
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, ib, nr, one, Z + r0, n, nn, V + (long)r0 * HNB, HNB, sV, zero, W, HNB, sW, batch); if (rc) return rc;
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, ib, ib, one, W, HNB, sW, Tm, HNB, sT, zero, W2, HNB, sW, batch); if (rc) return rc;
-        rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, n, nr, ib, mone, W2, HNB, sW, V + (long)r0 * HNB, HNB, sV, one, Z + r0, n, nn, batch); if (rc) return rc;
+        if (hg == 1) {
+            // (7-9) Z[:, R] -= ((Z[:, R] V[R,:]) T) V[R,:]^H
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, ib, nr, one, Z + r0, n, nn, V + (long)r0 * HNB, HNB, sV, zero, W, HNB, sW, batch); if (rc) return rc;
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, n, ib, ib, one, W, HNB, sW, Tm, HNB, sT, zero, W2, HNB, sW, batch); if (rc) return rc;
+            rc = gemm<T>(s, TRX_OP_N, TRX_OP_C, n, nr, ib, mone, W2, HNB, sW, V + (long)r0 * HNB, HNB, sV, one, Z + r0, n, nn, batch); if (rc) return rc;
+        } else {
+            // the panel joins its group; the rows of A above the group and Z get the merged reflector when the group is full (or the reduction ends)
+            TRX_LAUNCH((pack_group_kernel<T>), dim3(cdiv_i(n - g_r0, 8), batch), dim3(256), 0, s, (const cx<T>*)V, (const cx<T>*)Tm, B.Vg, B.Tg, n, g_r0, r0, ib, gp);
+            ++gp;
+            if (gp == hg || p0 + HNB >= n - 2) {
+                rc = hess_flush_group<T>(s, B, n, batch, g_r0, gp); if (rc) return rc;
+                gp = 0;
+            }
+        }
     }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
