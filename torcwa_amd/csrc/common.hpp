@@ -187,27 +187,6 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
 template <class T>
 int lu_factor(hipStream_t s, cx<T>* A, int lda, long sA, int n, int* piv, int batch, int* info);
 int lu_set_knob(const char* key, int value);          // trx_tuning("lu_split", rows)
-// XCD-aware tile order for tiled kernels with a (column tiles, row tiles, batch) grid.  The dispatcher is observed to place workgroup L (linear
-// id) on XCD L % 8, each XCD with its own 4 MiB L2: with the plain order the workgroups that share an operand tile are spread over all eight
-// L2s and every one of them fetches it across the fabric.  Here XCD c takes the c-th CONTIGUOUS eighth of the tiles (bijective for any grid),
-// and inside a matrix the tiles run through column panels of PW tiles, row by row: the workgroups resident on an XCD at one time cover a
-// compact rows x PW block of one matrix, so an operand slab crosses the fabric once per block instead of once per workgroup.  Placement is
-// a speed matter only (results do not depend on it).
-__device__ __forceinline__ void xcd_tile_order(int pw, int& bx, int& by, int& bz) {
-    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-    const unsigned per = gx * gy, total = per * gz;
-    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned q = total >> 3, r = total & 7u, c = L & 7u;
-    const unsigned Lp = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + (L >> 3);
-    const unsigned z = Lp / per, rem = Lp - z * per;
-    const unsigned full = gx / (unsigned)pw, per_full = (unsigned)pw * gy;
-    unsigned p = rem / per_full, x, y;
-    if (p < full) { const unsigned t = rem - p * per_full; y = t / (unsigned)pw; x = p * pw + (t - y * pw); }
-    else { const unsigned tw = gx - full * pw, t = rem - full * per_full; y = t / tw; x = full * pw + (t - y * tw); }
-    bx = (int)x; by = (int)y; bz = (int)z;
-}
-int gemm_xcd_order();                                  // 1 = XCD-aware tile order on (trx_tuning("gemm_xcd", 0 automatic = on / 1 = plain blockIdx order)
-
 // large-tile fp64 kernel (gemm_big.hip)
 void gemm_big_tile(int* bm, int* bn);
 int gemm_big(hipStream_t s, int opA, int opB, int m, int n, int k, cx<double> alpha, const cx<double>* A, int lda, long sA, const cx<double>* B,

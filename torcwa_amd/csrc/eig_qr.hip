@@ -979,8 +979,9 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         typename Mfma<T>::acc_t accR, accI;
+        [[maybe_unused]] typename Mfma<T>::acc_t accX;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); }
+        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); if (TRX_QR_VAR == 5) accX[r] = T(0); }
         const int cmax = band ? q + 1 : 3;              // last k chunk with a nonzero block in tile column q
         const T* ur = Ur + (KLS * lk) * MLD + lr + 16 * q;
         const T* ui = Ui + (KLS * lk) * MLD + lr + 16 * q;
@@ -991,13 +992,24 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
             for (int j = 0; j < 4; ++j) {
                 const T a = ur[(16 * c + j) * MLD], bq = ui[(16 * c + j) * MLD];
                 const cx<T> xv = x[4 * c + j];
+                if constexpr (TRX_QR_VAR == 5) {
+                    // 3M form of C = U^H X:  P1 = ur xr, P2 = ui xi, P3 = (ur - ui)(xr + xi);  Cr = P1 + P2,  Ci = P3 - P1 + P2
+                    accR = Mfma<T>::mma(a, xv.x, accR);
+                    accI = Mfma<T>::mma(bq, xv.y, accI);
+                    accX = Mfma<T>::mma(a - bq, xv.x + xv.y, accX);
+                } else {
                 // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr
                 accR = Mfma<T>::mma(a, xv.x, accR);
                 accI = Mfma<T>::mma(a, xv.y, accI);
                 accR = Mfma<T>::mma(bq, xv.y, accR);
                 accI = Mfma<T>::mma(bq, -xv.x, accI);
+                }
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);        // bounds the hoisting of the fragment reads (register budget)
             }
+        }
+        if constexpr (TRX_QR_VAR == 5) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const T p1 = accR[r], p2 = accI[r]; accR[r] = p1 + p2; accI[r] = accX[r] - p1 + p2; }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -29,7 +29,7 @@ constexpr int plane_of(int extent, bool k_contig, int bk) { return k_contig ? ex
 template <class T, int OPA, int OPB, int WR, int NT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, cx<T> alpha, const cx<T>* __restrict__ A, int lda, long sA,
                                                         const cx<T>* __restrict__ B, int ldb, long sB, cx<T> beta, cx<T>* __restrict__ C,
-                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper, int xcd) {
+                                                        int ldc, long sC, const GemmDesc* __restrict__ desc, int b_upper) {
     constexpr int LDK = BK + 2;
     constexpr int WC = 4 / WR;                   // waves along N
     constexpr int BM = 16 * WR, BN = 16 * NT * WC;
@@ -39,8 +39,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
     __shared__ T Ai[plane_of(BM, OPA == TRX_OP_N, BK)];
     __shared__ T Br[plane_of(BN, OPB != TRX_OP_N, BK)];
     __shared__ T Bi[plane_of(BN, OPB != TRX_OP_N, BK)];
-    int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
-    if (xcd) xcd_tile_order(BN >= 128 ? 4 : 8, bx, by, b);          // XCD-aware tile order (common.hpp); off for per-batch descriptors
+    const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
     C += (long)b * sC;
@@ -49,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
         m = d.m; n = d.n; k = d.k;
         A += d.offA; B += d.offB; C += d.offC;
     }
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= m || n0 >= n) return;
     if (b_upper && n0 + BN < k) k = n0 + BN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
     const int t = threadIdx.x;
@@ -176,26 +175,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(int m, int n, int k, 
 // (A 128 x 128 tile for large fp32 products -- same kernel shape, a wave owning 64 x 64, 249 registers -- was measured in round 6 and removed:
 // gemm<N,N> fp32 stayed at 0.55 of the fp32 matrix peak on the refinement's LU / solve products, and the rank-32 / 64 updates of the Hessenberg
 // reduction it also caught lost parallelism: that phase went from 909 to 982 ms.  profiles/r06_ab/r6i_ninth_call.txt)
+// (An XCD-aware tile order -- XCD c takes a contiguous eighth of the tiles, column panels of 4 / 8 tiles inside a matrix, for both kernels --
+// and the large tile on single full rows of tiles were measured in round 6 and removed: 35.85 / 35.88 layer-solves/s with the remap against
+// 36.14 / 35.98 in the plain blockIdx order, every GEMM tag within 1 %; neither kernel is bound by its L2 misses at these shapes.
+// profiles/r06_ab/r6m_xcd_tile_order.txt)
 // Large-tile fp64 kernel of gemm_big.hip (128 x 96 on 8 waves): trx_tuning("gemm_big", v) / TRX_GEMM_BIG, v = 0 automatic (= on), 4 = off (64 x 64
 // tile of this file everywhere).  Measured on MI355X at 1922^3 x 128 (profiles/r04_ab/r4_gemm_big.txt): 73.2 (off) / 85.2 TF-equivalent.
 static int gemm_big_env() { const char* e = getenv("TRX_GEMM_BIG"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 4) ? v : 0; }
 static int g_gemm_big = gemm_big_env();
-// XCD-aware tile order of both GEMM kernels (common.hpp: xcd_tile_order): trx_tuning("gemm_xcd", v) / TRX_GEMM_XCD, 0 automatic (= on), 1 = plain
-static int gemm_xcd_env() { const char* e = getenv("TRX_GEMM_XCD"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 1) ? v : 0; }
-static int g_gemm_xcd = gemm_xcd_env();
 
 template <class T, int OPA, int OPB>
 void launch_shape(hipStream_t s, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
                   const cx<T>* B, int ldb, long sB, cx<T> beta, cx<T>* C, int ldc, long sC, const GemmDesc* desc, int b_upper) {
-    const int xcd = (g_gemm_xcd == 0 && !desc) ? 1 : 0;
     // K-slab depth 16 everywhere.  A 32-deep slab for the general tile (half the barriers per flop, twice the prefetch distance) was
     // measured SLOWER on MI355X with the 3M product (70.9 vs 72.6 TF at 1922^3 x 128: 256 VGPRs, one spill); the template keeps it.
     if (shape == 1)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, xcd);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 2, 16>), dim3(cdiv_i(n, 32), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else if (shape == 2)
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, xcd);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 2, 4, 16>), dim3(cdiv_i(n, 128), cdiv_i(m, 32), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     else {
-        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper, xcd);
+        TRX_LAUNCH((gemm_mfma_kernel<T, OPA, OPB, 4, 4, 16>), dim3(cdiv_i(n, 64), cdiv_i(m, 64), batch), dim3(256), 0, s, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, desc, b_upper);
     }
 }
 
@@ -219,14 +218,8 @@ int gemm_set_knob(const char* key, int value) {
         g_gemm_big = value;
         return TRX_OK;
     }
-    if (std::string(key) == "gemm_xcd") {
-        if (value != 0 && value != 1) return TRX_ERR_ARG;
-        g_gemm_xcd = value;
-        return TRX_OK;
-    }
     return TRX_ERR_ARG;
 }
-int gemm_xcd_order() { return g_gemm_xcd == 0 ? 1 : 0; }
 
 template <class T>
 int launch_dispatch(hipStream_t s, int opA, int opB, int shape, int batch, int m, int n, int k, cx<T> alpha, const cx<T>* A, int lda, long sA,
@@ -259,10 +252,7 @@ int gemm(hipStream_t s, int opA, int opB, int m, int n, int k, cx<T> alpha, cons
         if (big) gemm_big_tile(&bm, &bn);
         // (its direct loads address an operand with 32-bit BYTE offsets from a scalar base: the operand's extent must stay below 4 GiB)
         const long exA = (long)(opA == TRX_OP_N ? m : k) * lda, exB = (long)(opB == TRX_OP_N ? k : n) * ldb;
-        // (one row of large tiles is enough when it is a full one -- the 128-row halves of the triangular solves, lu.hip -- and the batch and the
-        // columns supply the workgroups)
-        const bool rows_ok = m >= 2 * bm || (m >= bm && m % bm <= 32 && (long)(n / bn) * batch >= 512);
-        if (big && !desc && !b_upper && rows_ok && n >= 2 * bn && k >= 64 && exA < (1L << 28) && exB < (1L << 28)) {
+        if (big && !desc && !b_upper && m >= 2 * bm && n >= 2 * bn && k >= 64 && exA < (1L << 28) && exB < (1L << 28)) {
             const int rm = (m % bm) <= 32 ? m % bm : 0, rn = (n % bn) <= 32 ? n % bn : 0;
             const int mm = m - rm, nm = n - rn;
             int rc = gemm_big(s, opA, opB, mm, nm, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, 0);

@@ -58,7 +58,7 @@ struct BigCfg {
 template <int OPA, int OPB, int WM, int WN, int QTM, int QTN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(int m, int n, int k, cx<double> alpha, const cx<double>* __restrict__ A, int lda, long sA,
                                                       const cx<double>* __restrict__ B, int ldb, long sB, cx<double> beta, cx<double>* __restrict__ C,
-                                                      int ldc, long sC, int b_upper, int xcd) {
+                                                      int ldc, long sC, int b_upper) {
     typedef double T;
     typedef BigCfg<OPA, OPB, WM, WN, QTM, QTN> Cfg;
     constexpr int QBM = Cfg::QBM, QBN = Cfg::QBN, NW = Cfg::NW;
@@ -67,12 +67,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_big_kernel(i
     TRX_DYN_SMEM(smem);
     cx<T>* ring = reinterpret_cast<cx<T>*>(smem);
     cx<T>* scratch = ring + QST * STG;
-    int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
-    if (xcd) xcd_tile_order(4, bx, by, b);            // XCD-aware tile order (common.hpp): 32 resident workgroups per XCD = 8 rows x 4 columns of tiles
+    const int b = blockIdx.z;
     A += (long)b * sA;
     B += (long)b * sB;
     C += (long)b * sC;
-    const int m0 = by * QBM, n0 = bx * QBN;
+    const int m0 = blockIdx.y * QBM, n0 = blockIdx.x * QBN;
     if (b_upper && n0 + QBN < k) k = n0 + QBN;     // op(B) upper triangular: rows below the diagonal of this column tile are zero
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -269,7 +268,7 @@ int launch_big(hipStream_t s, int m, int n, int k, cx<double> alpha, const cx<do
         if (st == 2) return TRX_ERR_LAUNCH;
     }
     TRX_LAUNCH((gemm_big_kernel<OPA, OPB, WM, WN, QTM, QTN>), dim3(cdiv_i(n, Cfg::QBN), cdiv_i(m, Cfg::QBM), batch), dim3(64 * Cfg::NW), Cfg::smem, s, m, n, k, alpha,
-               A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper, gemm_xcd_order());
+               A, lda, sA, B, ldb, sB, beta, C, ldc, sC, b_upper);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
