@@ -979,9 +979,8 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         typename Mfma<T>::acc_t accR, accI;
-        [[maybe_unused]] typename Mfma<T>::acc_t accX;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); if (TRX_QR_VAR == 5) accX[r] = T(0); }
+        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); }
         const int cmax = band ? q + 1 : 3;              // last k chunk with a nonzero block in tile column q
         const T* ur = Ur + (KLS * lk) * MLD + lr + 16 * q;
         const T* ui = Ui + (KLS * lk) * MLD + lr + 16 * q;
@@ -992,24 +991,14 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
             for (int j = 0; j < 4; ++j) {
                 const T a = ur[(16 * c + j) * MLD], bq = ui[(16 * c + j) * MLD];
                 const cx<T> xv = x[4 * c + j];
-                if constexpr (TRX_QR_VAR == 5) {
-                    // 3M form of C = U^H X:  P1 = ur xr, P2 = ui xi, P3 = (ur - ui)(xr + xi);  Cr = P1 + P2,  Ci = P3 - P1 + P2
-                    accR = Mfma<T>::mma(a, xv.x, accR);
-                    accI = Mfma<T>::mma(bq, xv.y, accI);
-                    accX = Mfma<T>::mma(a - bq, xv.x + xv.y, accX);
-                } else {
-                // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr
+                // C = U^H X:    Cr += ur xr + ui xi,  Ci += ur xi - ui xr     (the 3M form -- P1 = ur xr, P2 = ui xi, P3 = (ur - ui)(xr + xi) -- was
+                // measured in the fused launches in round 6: QR phase 919 / 920 against 904 / 906 ms; profiles/r06_ab/r6n_left_update_3m.txt)
                 accR = Mfma<T>::mma(a, xv.x, accR);
                 accI = Mfma<T>::mma(a, xv.y, accI);
                 accR = Mfma<T>::mma(bq, xv.y, accR);
                 accI = Mfma<T>::mma(bq, -xv.x, accI);
-                }
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);        // bounds the hoisting of the fragment reads (register budget)
             }
-        }
-        if constexpr (TRX_QR_VAR == 5) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const T p1 = accR[r], p2 = accI[r]; accR[r] = p1 + p2; accI[r] = accX[r] - p1 + p2; }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1040,23 +1029,39 @@ __device__ void left_links_strips(cx<T>* __restrict__ H, int n, const QrLink* __
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int UPT = QW * QW / WTHREADS;
-    for (int i = 0; i < pnq; ++i) {
-        const QrLink l = lks[(long)i * kc];
-        const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
-        const int e = __builtin_amdgcn_readfirstlane(l.e);
-        const int ww = w1 - w0;
-        if (kind != QRL_CHASE || ww <= 0) continue;
-        const int nL = n > e ? (n - e + 15) >> 4 : 0;
-        const int lim = g1 < nL ? g1 : nL;
-        if (g0 >= lim) continue;                             // (workgroup-uniform)
+    // links this workgroup has strips for (workgroup-uniform test); the window unitary of the NEXT such link is fetched into registers before the
+    // strips of the current one are worked on, so that its latency is not exposed between two links (round 6)
+    int e_i = 0, w0_i = 0, ww_i = 0, lim_i = 0;
+    auto next_link = [&](int from) {
+        for (int i = from; i < pnq; ++i) {
+            const QrLink l = lks[(long)i * kc];
+            const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
+            const int e = __builtin_amdgcn_readfirstlane(l.e);
+            const int ww = w1 - w0;
+            if (kind != QRL_CHASE || ww <= 0) continue;
+            const int nL = n > e ? (n - e + 15) >> 4 : 0;
+            const int lim = g1 < nL ? g1 : nL;
+            if (g0 >= lim) continue;
+            e_i = e; w0_i = w0; ww_i = ww; lim_i = lim;
+            return i;
+        }
+        return pnq;
+    };
+    cx<T> ureg[UPT];
+    auto fetch_u = [&](int i, int ww) {
         const cx<T>* U = Ulog + (long)i * kc * QW * QW;
-        cx<T> ureg[UPT];
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
             ureg[q] = U[(k < ww ? k : ww - 1) * QW + (c < ww ? c : ww - 1)];
         }
-        if (t == 0) vote[i & 1] = 0;
+    };
+    int i = next_link(0);
+    if (i < pnq) fetch_u(i, ww_i);
+    for (int it = 0; i < pnq; ++it) {                        // it: processed links (the two vote slots alternate strictly, whatever is skipped)
+        const int e = e_i, w0 = w0_i, ww = ww_i, lim = lim_i;
+        const int vi = it & 1;
+        if (t == 0) vote[vi] = 0;
         __syncthreads();                                     // the previous link's readers are done with the planes
         int dense = 0;
 #pragma unroll
@@ -1067,9 +1072,11 @@ __device__ void left_links_strips(cx<T>* __restrict__ H, int n, const QrLink* __
             Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
             if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
         }
-        if (dense) vote[i & 1] = 1;
+        if (dense) vote[vi] = 1;
+        i = next_link(i + 1);
+        if (i < pnq) fetch_u(i, ww_i);                      // in flight under this link's strips
         __syncthreads();
-        const bool band = band_on && vote[i & 1] == 0;
+        const bool band = band_on && vote[vi] == 0;
         int mine = 0;
         for (int g = g0 + wave; g < lim; g += gs) {
             SlabStrip<T> d;
