@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 6, sixteenth GPU call: bulge chains per sweep (1 / 2 / 3) at small batches -- which batches should leave the one-chain super-step path.
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+O=gpurun_out/r6_call16.txt
+: > $O
+line() { python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; ph={p['phase'].split('/')[-1].strip(): round(p['ms_per_step']) for p in r['phases']['inside_trx_eig']}
+    print(round(d['value'],4), d['unit'], round(d['ms_per_step'],1), 'ms', d.get('numerical_failures'), ph)
+except Exception as e: print('FAILED', e)"; }
+run() { echo -n "$* B=${B:-128} ${FLAGS}: " >> $O; env "$@" timeout 400 python bench.py --batch ${B:-128} --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg ${FLAGS} 2>>gpurun_out/r6_call16.err | line >> $O; }
+for b in 8 16 24 32 48; do
+  for c in 1 2 3; do B=$b run TRX_QR_CHAINS=$c; done
+done
+B=16 run TRX_QR_CHAINS=2 TRX_QR_AED=64
+B=16 run TRX_QR_CHAINS=2 TRX_QR_GROUPS=4
+B=16 run TRX_QR_CHAINS=2 TRX_QR_GROUPS=1
+cat $O | cut -c1-300

@@ -1029,39 +1029,25 @@ __device__ void left_links_strips(cx<T>* __restrict__ H, int n, const QrLink* __
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int UPT = QW * QW / WTHREADS;
-    // links this workgroup has strips for (workgroup-uniform test); the window unitary of the NEXT such link is fetched into registers before the
-    // strips of the current one are worked on, so that its latency is not exposed between two links (round 6)
-    int e_i = 0, w0_i = 0, ww_i = 0, lim_i = 0;
-    auto next_link = [&](int from) {
-        for (int i = from; i < pnq; ++i) {
-            const QrLink l = lks[(long)i * kc];
-            const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
-            const int e = __builtin_amdgcn_readfirstlane(l.e);
-            const int ww = w1 - w0;
-            if (kind != QRL_CHASE || ww <= 0) continue;
-            const int nL = n > e ? (n - e + 15) >> 4 : 0;
-            const int lim = g1 < nL ? g1 : nL;
-            if (g0 >= lim) continue;
-            e_i = e; w0_i = w0; ww_i = ww; lim_i = lim;
-            return i;
-        }
-        return pnq;
-    };
-    cx<T> ureg[UPT];
-    auto fetch_u = [&](int i, int ww) {
+    // (Fetching the NEXT link's window unitary into registers under the current link's strips was measured in round 6: QR phase 927 / 932 against
+    // 894 / 894 ms at batch 128, 627 against 607 at batch 64 -- removed; profiles/r06_ab/r6o_u_prefetch_and_chains.txt)
+    for (int i = 0; i < pnq; ++i) {
+        const QrLink l = lks[(long)i * kc];
+        const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
+        const int e = __builtin_amdgcn_readfirstlane(l.e);
+        const int ww = w1 - w0;
+        if (kind != QRL_CHASE || ww <= 0) continue;
+        const int nL = n > e ? (n - e + 15) >> 4 : 0;
+        const int lim = g1 < nL ? g1 : nL;
+        if (g0 >= lim) continue;                             // (workgroup-uniform)
         const cx<T>* U = Ulog + (long)i * kc * QW * QW;
+        cx<T> ureg[UPT];
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
             ureg[q] = U[(k < ww ? k : ww - 1) * QW + (c < ww ? c : ww - 1)];
         }
-    };
-    int i = next_link(0);
-    if (i < pnq) fetch_u(i, ww_i);
-    for (int it = 0; i < pnq; ++it) {                        // it: processed links (the two vote slots alternate strictly, whatever is skipped)
-        const int e = e_i, w0 = w0_i, ww = ww_i, lim = lim_i;
-        const int vi = it & 1;
-        if (t == 0) vote[vi] = 0;
+        if (t == 0) vote[i & 1] = 0;
         __syncthreads();                                     // the previous link's readers are done with the planes
         int dense = 0;
 #pragma unroll
@@ -1072,11 +1058,9 @@ __device__ void left_links_strips(cx<T>* __restrict__ H, int n, const QrLink* __
             Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
             if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
         }
-        if (dense) vote[vi] = 1;
-        i = next_link(i + 1);
-        if (i < pnq) fetch_u(i, ww_i);                      // in flight under this link's strips
+        if (dense) vote[i & 1] = 1;
         __syncthreads();
-        const bool band = band_on && vote[vi] == 0;
+        const bool band = band_on && vote[i & 1] == 0;
         int mine = 0;
         for (int g = g0 + wave; g < lim; g += gs) {
             SlabStrip<T> d;
