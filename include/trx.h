@@ -93,8 +93,9 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  * value out of range.  Unless stated otherwise value 0 = automatic (chosen from n and the batch size).
  *   QR phase of trx_eig
  *   "qr_groups"   1-8   iteration groups on their own streams (TRX_QR_GROUPS)        auto: 4 (batch >= 64), 2 (batch >= 8), 1
- *   "qr_aed"      16-64 aggressive-early-deflation window (TRX_QR_AED)                auto: 64 (batch >= 64 or <= 2), else 48
- *   "qr_chains"   1-3   bulge chains per sweep (TRX_QR_CHAINS)                        auto: 1, and 3 for batch <= 2
+ *   "qr_aed"      16-64 aggressive-early-deflation window (TRX_QR_AED)                auto: 64; 48 for one chain per sweep below batch 64
+ *   "qr_chains"   1-3   bulge chains per sweep (TRX_QR_CHAINS)                        auto: 3 for batch <= 2, 2 up to batch 48, 1 above (one chain =
+ *                       the form with super-steps and fused launches, which pays when the batch fills the chip)
  *   "qr_nibble"   0-100 LITERAL percentage, default 100 (TRX_QR_NIBBLE): an AED that deflated less than this share of its window is
  *                       followed by a sweep in the same outer iteration; 0 switches that sweep off.  No automatic value.
  *   "qr_moves"    0-64  LITERAL bound, default 12 (TRX_QR_MOVES): undeflatable eigenvalues an AED moves out of the way; 0 = no reordering.

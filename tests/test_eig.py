@@ -157,10 +157,10 @@ def test_eig_deferred_right_update(backend, spw):
     A[2] = 0.2 * A[2] + np.diag(np.linspace(-9, 9, n)).astype(np.complex128)
     A[1][n // 2:, :n // 2] = 0                                     # block upper triangular: two independent active blocks
     try:
-        _set_knobs(be, slab_spw=spw)
+        _set_knobs(be, slab_spw=spw, qr_chains=1)             # one chain per sweep: the form with super-steps (automatic above batch 48 only)
         w, V, info = run_eig(be, A)
     finally:
-        _set_knobs(be, slab_spw=0)
+        _set_knobs(be, slab_spw=0, qr_chains=0)
     check(A, w, V, info, 1e-12)
 
 
@@ -187,23 +187,23 @@ def test_eig_hessenberg_delayed_right_updates(backend, group):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, slab_spw=2), dict(qr_super=1), dict(qr_super=3, slab_band=1)])
+@pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, slab_spw=2), dict(qr_super=1), dict(qr_super=3, slab_band=1), dict(qr_super=4, qr_fuse=1)])
 def test_eig_super_steps_fp32(backend, knobs):
     """fp32 QR phase (first stage of the mixed-precision route; complex64 problems under precision="native"): a launch of the window kernel
     takes the chain through up to 8 windows, applying each window's unitary itself to the band of columns the following windows slide
     over; the left update beyond the band is one launch per super-step over its links, the right / Z update one launch per sweep.  Sizes
     with several super-steps per sweep; a spread spectrum (early deflations move the active block) next to a dense matrix."""
-    if backend == "emu" and knobs != dict(qr_super=4):
-        pytest.skip("emulator time budget: the default super-step length only")
+    if backend == "emu" and knobs not in (dict(qr_super=4), dict(qr_super=4, qr_fuse=1)):
+        pytest.skip("emulator time budget: the default super-step length only (fused launches, and the left update as its own launch)")
     be = get_backend(backend)
     n = 200 if backend == "emu" else 450
     A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex64)
     A[1] = (0.3 * A[1] + np.diag(np.linspace(-12, 12, n))).astype(np.complex64)
     try:
-        _set_knobs(be, **knobs)
+        _set_knobs(be, qr_chains=1, **knobs)                  # one chain per sweep (automatic above batch 48 only): super-steps need it
         w, V, info = run_eig(be, A)
     finally:
-        _set_knobs(be, **{k: 0 for k in knobs})
+        _set_knobs(be, qr_chains=0, **{k: 0 for k in knobs})
     check(A, w, V, info, 5e-6)
 
 
@@ -266,22 +266,26 @@ def test_eig_nonfinite_input_fails_fast(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_eig_balances_badly_scaled_input(backend):
+@pytest.mark.parametrize("seed", [1, 2, 4])
+def test_eig_balances_badly_scaled_input(backend, seed):
     """zgebal parity (torch.linalg.eig -> zgeev balances first): A = D A0 D^-1 with D = 2^k, k in [-24, 24], has the eigenvalues
     of the well-scaled A0, but entries spread over 28 orders of magnitude; an unbalanced QR iteration loses the small eigenvalues
     to the norm of A (eps * 2^48 ~ 6e-2), the balanced one recovers them like LAPACK does.  Also: a matrix that is already
     balanced must come through bit-identical scaling (D = I), and a batch mixes both kinds."""
     be = get_backend(backend)
     n = 48
-    A0 = RNG.standard_normal((n, n)) + 1j * RNG.standard_normal((n, n)) + np.diag(4.0 * np.arange(n))
-    k = RNG.integers(-24, 25, size=n)
+    # own generator: the three seeds are the ones (of 0 .. 7) on which the incrementally maintained row / column sums of round 6 first lost
+    # their digits to cancellation (eigenvalues 1e-13 .. 4e-13 off, 3e-10 in the suite's shared stream) before stale sums were recomputed
+    rng = np.random.default_rng(seed)
+    A0 = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + np.diag(4.0 * np.arange(n))
+    k = rng.integers(-24, 25, size=n)
     D = 2.0 ** k
     A = np.stack([(D[:, None] * A0) / D[None, :], A0]).astype(np.complex128)
     w, V, info = run_eig(be, A)
     assert info[0] == 0 and info[1] == 0
     wref, Vref = np.linalg.eig(A0)
-    assert match_eigs(w[0], wref) / np.abs(wref).max() < 1e-12
-    assert match_eigs(w[1], wref) / np.abs(wref).max() < 1e-12
+    assert match_eigs(w[0], wref) / np.abs(wref).max() < 1e-13
+    assert match_eigs(w[1], wref) / np.abs(wref).max() < 1e-13
     # eigenvectors of the scaled matrix: columns of D V0, unit 2-norm (zgebak + normalisation)
     for j in range(n):
         i = int(np.argmin(np.abs(wref - w[0][j])))

@@ -116,18 +116,38 @@ __global__ __launch_bounds__(BST) void bal_seq_kernel(const float* __restrict__ 
     T* d2 = reinterpret_cast<T*>(smem);          // [n]   d_j^2
     T* Rs = d2 + n;                              // [n]   sum_j |a_ij|^2 d_j^2
     T* Cs = Rs + n;                              // [n]   sum_j |a_ji|^2 / d_j^2
+    unsigned char* stale = reinterpret_cast<unsigned char*>(Cs + n);     // [n]   the running sums of this index have lost their digits (see below)
     __shared__ int changed;
     __shared__ T upd[2];                         // (w' - w, 1/w' - 1/w) of the index being scaled; upd[0] == 0: left alone
+    __shared__ T part[2][BST / 64];
     const int b = blockIdx.x, t = threadIdx.x;
     if (!need[b]) return;
     const float* M2 = M2all + (long)b * n * n;
     const float* M2T = M2Tall + (long)b * n * n;
-    for (int j = t; j < n; j += BST) { d2[j] = T(1); Rs[j] = r2all[(long)b * n + j]; Cs[j] = c2all[(long)b * n + j]; }
+    for (int j = t; j < n; j += BST) { d2[j] = T(1); Rs[j] = r2all[(long)b * n + j]; Cs[j] = c2all[(long)b * n + j]; stale[j] = 0; }
     __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (t == 0) changed = 0;
         __syncthreads();
         for (int i = 0; i < n; ++i) {
+            // A running sum is only as good as what was taken out of it: when the scaling of index k removes a term that dominated R_i or C_i
+            // (the badly scaled matrices balancing exists for: entries 2^96 apart in |a|^2), what is left is the rounding error of the
+            // removed term -- in the float copy 6e-8 of it.  Such an index is marked, and its two sums are recomputed from row i of |A|^2
+            // and of its transpose (contiguous) when its turn comes.  (Found by tests/test_eig.py::test_eig_balances_badly_scaled_input at a
+            // new position of the test's random stream: eigenvalues 3e-10 off where LAPACK's balancing gives 1e-14.)
+            if (stale[i]) {                      // (workgroup-uniform: written before the last barrier)
+                T sr = T(0), sc = T(0);
+                for (int k = t; k < n; k += BST) { sr += (T)M2[(long)i * n + k] * d2[k]; sc += (T)M2T[(long)i * n + k] / d2[k]; }
+                sr = wave_sum(sr); sc = wave_sum(sc);
+                if ((t & 63) == 0) { part[0][t >> 6] = sr; part[1][t >> 6] = sc; }
+                __syncthreads();
+                if (t == 0) {
+                    T a = T(0), c = T(0);
+                    for (int q = 0; q < BST / 64; ++q) { a += part[0][q]; c += part[1][q]; }
+                    Rs[i] = a; Cs[i] = c; stale[i] = 0;
+                }
+                __syncthreads();
+            }
             if (t == 0) {
                 const T w = d2[i];
                 const T f = bal_factor<T>(sqrt(Cs[i] * w), sqrt(Rs[i] / w), sqrt(w));
@@ -142,8 +162,12 @@ __global__ __launch_bounds__(BST) void bal_seq_kernel(const float* __restrict__ 
             if (dw != T(0)) {                    // (workgroup-uniform)
                 const T diw = upd[1];
                 for (int k = t; k < n; k += BST) {
-                    Rs[k] += (T)M2T[(long)i * n + k] * dw;          // |a_ki|^2: column i of |A|^2 = row i of its transpose
-                    Cs[k] += (T)M2[(long)i * n + k] * diw;          // |a_ik|^2: row i
+                    const T mr = (T)M2T[(long)i * n + k] * dw;          // |a_ki|^2: column i of |A|^2 = row i of its transpose
+                    const T mc = (T)M2[(long)i * n + k] * diw;          // |a_ik|^2: row i
+                    const T r = Rs[k] + mr, c = Cs[k] + mc;
+                    // a removed term more than 1000 x what remains: fewer than four digits of the float copy are left
+                    if ((mr < T(0) && !(r > T(1e-3) * -mr)) || (mc < T(0) && !(c > T(1e-3) * -mc))) stale[k] = 1;
+                    Rs[k] = r; Cs[k] = c;
                 }
             }
             __syncthreads();
@@ -177,7 +201,7 @@ int balance(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     T* r2 = B.bal_w;                       // [2][B,n]: r2, c2
     T* c2 = r2 + (long)batch * n;
     int* need = B.bal_flags;               // [B] matrix needs balancing
-    const size_t smq = sizeof(T) * 3 * (size_t)n;
+    const size_t smq = sizeof(T) * 3 * (size_t)n + ((size_t)n + 15) / 16 * 16;        // d^2, R, C + the stale marks
     // |A|^2 and its transpose as float: 8 n^2 bytes per matrix, in Z (16 / 8 n^2 bytes per matrix, first written by the Hessenberg reduction)
     float* M2 = reinterpret_cast<float*>(B.Z);
     float* M2T = M2 + (long)batch * n * n;

@@ -1538,7 +1538,12 @@ static QrKnobs& qr_knobs() {
 }
 
 // Bulge chains per sweep and slots of the link log: the workspace layout (eig.hip) and the solver must agree on both.
-int qr_chains_for(int batch) { const QrKnobs& K = qr_knobs(); return K.chains ? K.chains : (batch <= 2 ? QKC : 1); }
+// Bulge chains per sweep.  Automatic: 3 for one or two matrices, 2 up to batch 48, 1 above.  One chain per sweep is the form with super-steps,
+// fused launches and the right / Z update once per sweep -- throughput machinery that pays when the batch fills the chip; below that the QR
+// phase is its chain of dependent launches, and two chains (32 shifts per sweep, AED window 64) halve the number of sweeps.  Measured in round 6
+// (layer-solves/s, one chain / two chains with the 64-wide window): batch 4: 4.03 / 5.24, 8: 10.43 / 11.73, 16: 16.76 / 17.85, 24: 20.95 / 21.83,
+// 32: 24.13 / 24.89, 48: 27.91 / 28.04 (profiles/r06_ab/r6p_chains_small_batches.txt, r6q_chains_aed_small_batches.txt).
+int qr_chains_for(int batch) { const QrKnobs& K = qr_knobs(); return K.chains ? K.chains : (batch <= 2 ? QKC : (batch <= 48 ? 2 : 1)); }
 int qr_log_slots(int n) { return cdiv_i(n + 2 * QNS, QW - 2 * QNS - 1) + 2 + 4 * (QKC - 1) + 1; }
 
 // Non-blocking streams and timing-less events for the iteration groups, created on first use and kept for the life of the
@@ -1696,7 +1701,7 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // AED window: 64 deflates most per call (fewest sweeps, least update work) but costs 3 ms of single-wave latency; at small
     // batches, where nothing is throughput bound, a smaller window shortens the chain
     const long mstride = (long)ngroups * n * n;              // distance between consecutive matrices of one group
-    const int aed_w = K.aed ? K.aed : ((batch >= 64 || batch <= 2) ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48; batch 1 with 3 chains: 64
+    const int aed_w = K.aed ? K.aed : ((batch >= 64 || kc >= 2) ? QAED : 48);     // measured: batch 128: 64 -> 28.4, 48 -> 27.8 solves/s; batch 16: 48; batch 1 with 3 chains: 64
     const size_t smp = smp_of(aed_w);
     // LAPACK skips the sweep when AED deflated more than 14 % of the window ("nibble") because there the sweep is the expensive
     // part.  Here the AED is, so every AED that leaves an active block is followed by a sweep in the same iteration.
