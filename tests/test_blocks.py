@@ -273,6 +273,40 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_lu_panel_sub_blocks(backend, dtype):
+    """The one-workgroup panel with LDS-resident sub-blocks of 8 columns (knob lu_sub = 0; 4 columns for panels too tall for 8: forced
+    everywhere by lu_sub = 2) against the column-by-column panel of rounds 1 - 5 (lu_sub = 1): same pivots, factors equal to rounding, the
+    solve within the backward-error class.  Several outer blocks and a ragged last panel."""
+    be = get_backend(backend)
+    n, batch = (300, 2) if backend == "emu" else (1500, 3)
+    rng = np.random.default_rng(77)
+    A = (rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))).astype(dtype)
+    A[0, :, 5] *= 1e-3
+    Bm = (rng.standard_normal((batch, n, 7)) + 1j * rng.standard_normal((batch, n, 7))).astype(dtype)
+    res = {}
+    for sub in (1, 0, 2):
+        assert be.lib.tuning(b"lu_sub", sub) == 0 and be.lib.tuning(b"lu_split", 1) == 0          # never the row-split kernels here
+        try:
+            dA, dB = be.dev(A), be.dev(Bm)
+            piv, info = be.empty((batch, n), np.int32), be.dev(np.full((batch,), -7, dtype=np.int32))
+            assert be.lib.lu_solve(dtcode(dtype), be.ptr(dA), n, be.ptr(dB), 7, batch, be.ptr(piv), be.ptr(info), be.stream) == 0
+        finally:
+            be.lib.tuning(b"lu_sub", 0); be.lib.tuning(b"lu_split", 0)
+        assert (be.host(info) == 0).all()
+        res[sub] = (be.host(dA), be.host(dB), be.host(piv))
+    tol = 1e-12 if dtype == np.complex128 else 2e-4
+    A128, B128 = A.astype(np.complex128), Bm.astype(np.complex128)
+    for sub in (0, 2):
+        assert (res[sub][2] == res[1][2]).all()
+        assert np.abs(res[sub][0] - res[1][0]).max() / np.abs(res[1][0]).max() < tol
+    for sub in (1, 0, 2):
+        X = res[sub][1].astype(np.complex128)
+        berr = np.abs(A128 @ X - B128).max() / (np.abs(A128).max() * np.abs(X).max() * n)
+        assert berr < (1e-15 if dtype == np.complex128 else 1e-6), (sub, berr)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_lu_row_split_singular_info(backend):
     be = get_backend(backend)
     n = 300

@@ -108,9 +108,10 @@ __global__ __launch_bounds__(512) void lu_panel_kernel(cx<T>* __restrict__ Aall,
 // search, row swaps, rank-1 updates: LDS round trips and barriers only; the swaps reach the other columns of the panel in global memory), the
 // multipliers are scaled in LDS, the sub-block goes back, and the rest of the panel receives the sub-block's contribution in ONE rank-PSB pass
 // with the multipliers still in LDS.  Same pivots, same arithmetic up to the order of the updates.  Used while rows x PSB fits the LDS budget.
-constexpr int PSB = 8;
+// Sub-blocks of 8 columns while rows x 9 elements fit (fp64: 1094 rows, fp32: 2189), of 4 columns up to twice that (fp64: 1971 rows -- the
+// whole n = 1922 factorisation of the bench shape -- fp32: 3942); taller panels go to the row-split kernels below.
 constexpr int PLT = 512;
-template <class T>
+template <class T, int PSB>
 __global__ __launch_bounds__(PLT) void lu_panel_lds_kernel(cx<T>* __restrict__ Aall, int lda, long sA, int n, int k0, int jb,
                                                             int* __restrict__ piv_all, int* __restrict__ info_all) {
     TRX_DYN_SMEM(smem);
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(PLT) void lu_panel_lds_kernel(cx<T>* __restrict__ A
 }
 
 // opt-in to the large dynamic LDS of lu_panel_lds_kernel: once per device and dtype, a failure is remembered (the old kernel then serves)
-constexpr size_t PANEL_LDS_MAX = 150 * 1024;
-template <class T>
+constexpr size_t PANEL_LDS_MAX = 154 * 1024;          // + < 5 KB of static LDS (U rows, reciprocals, reduction scratch) = the CU's 160 KB
+template <class T, int PSB>
 static bool panel_lds_ready() {
     static std::mutex mu;
     static int state[64];               // 0 = not yet set, 1 = ok, 2 = failed
@@ -236,7 +237,7 @@ static bool panel_lds_ready() {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     int& st = state[dev & 63];
-    if (st == 0) st = set_max_dyn_smem((const void*)lu_panel_lds_kernel<T>, PANEL_LDS_MAX) ? 2 : 1;
+    if (st == 0) st = set_max_dyn_smem((const void*)lu_panel_lds_kernel<T, PSB>, PANEL_LDS_MAX) ? 2 : 1;
     return st == 1;
 }
 
@@ -683,9 +684,10 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
 // re-reads and re-writes the trailing matrix).
 constexpr int NBO = 8 * NB;
 
-static int lu_sub_env() { const char* e = getenv("TRX_LU_SUB"); const int v = e ? atoi(e) : 0; return (v == 0 || v == 1) ? v : 0; }
-static int g_lu_sub = lu_sub_env();       // trx_tuning("lu_sub", v): 0 = panels in sub-blocks of 8 columns (default), 1 = column by column as in rounds 1 - 5
-static int g_lu_split_rows = 0;           // 0 = automatic (1024); trx_tuning("lu_split", rows); 1 = never split
+static int lu_sub_env() { const char* e = getenv("TRX_LU_SUB"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }
+static int g_lu_sub = lu_sub_env();       // trx_tuning("lu_sub", v): 0 = panels in sub-blocks of 8 (4: tall panels) columns (default), 1 = column by column as in rounds 1 - 5, 2 = sub-blocks of 4 everywhere (tests)
+static int lu_split_rows_env() { const char* e = getenv("TRX_LU_SPLIT"); const int v = e ? atoi(e) : 0; return v >= 0 ? v : 0; }
+static int g_lu_split_rows = lu_split_rows_env();   // 0 = automatic (panels too tall for the LDS-resident kernel); trx_tuning("lu_split", rows) / TRX_LU_SPLIT; 1 = never split
 static int lu_split_batch_env() { const char* e = getenv("TRX_LU_SPLIT_BATCH"); return e ? atoi(e) : 0; }
 static int g_lu_split_batch = lu_split_batch_env();          // 0 = automatic (any batch): largest batch the split panel is used for; trx_tuning("lu_split_batch", b)
 int lu_set_knob(const char* key, int value) {
@@ -693,7 +695,7 @@ int lu_set_knob(const char* key, int value) {
     if (value < 0 || value > (1 << 20)) return TRX_ERR_ARG;
     if (k == "lu_split") g_lu_split_rows = value;
     else if (k == "lu_split_batch") g_lu_split_batch = value;
-    else if (k == "lu_sub") { if (value > 1) return TRX_ERR_ARG; g_lu_sub = value; }
+    else if (k == "lu_sub") { if (value > 2) return TRX_ERR_ARG; g_lu_sub = value; }
     else return TRX_ERR_ARG;
     return TRX_OK;
 }
@@ -712,10 +714,14 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
         const int jb = (Kend - c0 < NB) ? (Kend - c0) : NB;
         // few large matrices: row-split panel (see above); needs 2 W ints of the pivot array's unwritten tail
         const int rows = n - c0;
-        const int split_min = g_lu_split_rows ? g_lu_split_rows : 1024;
+        // one workgroup per matrix with the sub-block in LDS whenever it fits (sub-blocks of 8 columns, of 4 for panels twice as tall):
+        // ~5 - 9 us per column at any batch size, where the row-split kernels take 35 (fp64, batch 128: 21 per column launch + 12 for
+        // the sub-block passes + the scaling).  lu_split = rows (explicit): the row-split panel from that height on, as in rounds 3 - 5.
+        const int psb = g_lu_sub == 1 ? 0 : (g_lu_sub != 2 && sizeof(cx<T>) * (size_t)rows * 9 <= PANEL_LDS_MAX && panel_lds_ready<T, 8>()) ? 8
+                        : (sizeof(cx<T>) * (size_t)rows * 5 <= PANEL_LDS_MAX && panel_lds_ready<T, 4>()) ? 4 : 0;
+        const int split_min = g_lu_split_rows ? g_lu_split_rows : (psb ? (1 << 30) : 1024);
         // workgroups per matrix: about 512 per launch over the batch, at least 64 rows each (a larger batch already supplies
         // workgroups, but the one-workgroup panel still leaves half of the CUs idle at batch 128: knob lu_split_batch)
-        // measured on MI355X (round 3): the row-split panel also wins at batch 16 and 128 (+1.3 % of the whole layer-solve step each)
         const int split_batch = g_lu_split_batch ? g_lu_split_batch : (1 << 20);
         int W = rows / 64 < LSW_MAX ? rows / 64 : LSW_MAX;
         const int wcap = 512 / batch > 2 ? 512 / batch : 2;
@@ -737,9 +743,10 @@ int lu_block_panels(hipStream_t s, cx<T>* A, int lda, long sA, int n, int K0, in
             TRX_LAUNCH((lu_split_final_kernel<T>), dim3(batch), dim3(64), 0, s, A, lda, sA, n, c0, jb, piv);
         } else {
             ProfScope prof(PROF_LU_PANEL, s, 0, 0);
-            const size_t sm_p = sizeof(cx<T>) * (size_t)(n - c0) * (PSB + 1);
-            if (g_lu_sub != 1 && sm_p <= PANEL_LDS_MAX && panel_lds_ready<T>())
-                TRX_LAUNCH((lu_panel_lds_kernel<T>), dim3(batch), dim3(PLT), sm_p, s, A, lda, sA, n, c0, jb, piv, info);
+            if (psb == 8)
+                TRX_LAUNCH((lu_panel_lds_kernel<T, 8>), dim3(batch), dim3(PLT), sizeof(cx<T>) * (size_t)rows * 9, s, A, lda, sA, n, c0, jb, piv, info);
+            else if (psb == 4)
+                TRX_LAUNCH((lu_panel_lds_kernel<T, 4>), dim3(batch), dim3(PLT), sizeof(cx<T>) * (size_t)rows * 5, s, A, lda, sA, n, c0, jb, piv, info);
             else
                 TRX_LAUNCH((lu_panel_kernel<T>), dim3(batch), dim3(512), 0, s, A, lda, sA, n, c0, jb, piv, info);
         }
