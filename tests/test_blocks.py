@@ -247,10 +247,11 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
     """The row-split panel (few large matrices: W workgroups per matrix, one launch per panel column, implicit pivoting inside the
     panel) against numpy, and against the one-workgroup panel: same pivots (no exact ties in random data), same factors."""
     be = get_backend(backend)
-    A = crand((batch, n, n), dtype)
+    rng = np.random.default_rng(4000 + n)          # own generator: the data must not depend on which tests ran before
+    A = (rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))).astype(dtype)
     A[0, :, 0] *= 1e-3
     A[0, 7, :] *= 50.0              # a row that wins several pivot searches in a row
-    B = crand((batch, n, 9), dtype)
+    B = (rng.standard_normal((batch, n, 9)) + 1j * rng.standard_normal((batch, n, 9))).astype(dtype)
     res = []
     for split in (128, 1):          # 128: split while >= 128 rows remain; 1: never
         assert be.lib.tuning(b"lu_split", split) == 0 and be.lib.tuning(b"lu_split_batch", 16) == 0
@@ -268,8 +269,8 @@ def test_lu_row_split_panel(backend, dtype, tol, n, batch):
         assert np.abs(Xg - X).max() / np.abs(X).max() < tol
     assert (res[0][2] == res[1][2]).all()
     # same pivots, so the factors agree to rounding: reductions in another order differ by a few n eps (fp32: 1.6e-5 measured at n = 300;
-    # fp64: 1.06e-13 at n = 530 on MI355X -- the test data depend on the RNG position, i.e. on the tests that ran before)
-    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < (1e-12 if dtype == np.complex128 else 1e-4)
+    # fp64: 1.06e-13 at n = 530 on MI355X)
+    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < 20 * n * np.finfo(dtype).eps
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -295,7 +296,7 @@ def test_lu_panel_sub_blocks(backend, dtype):
             be.lib.tuning(b"lu_sub", 0); be.lib.tuning(b"lu_split", 0)
         assert (be.host(info) == 0).all()
         res[sub] = (be.host(dA), be.host(dB), be.host(piv))
-    tol = 1e-12 if dtype == np.complex128 else 2e-4
+    tol = 20 * n * np.finfo(dtype).eps              # factors of the same pivot sequence: the update order differs, errors grow with n (3.4e-4 seen in fp32 at n = 1500)
     A128, B128 = A.astype(np.complex128), Bm.astype(np.complex128)
     for sub in (0, 2):
         assert (res[sub][2] == res[1][2]).all()
