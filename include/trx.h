@@ -121,9 +121,11 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *   "gemm_big"    4 = large-tile complex128 kernel (128 x 96 on 8 waves; outputs of at least 2 x 2 tiles, k >= 64) OFF: the 64 x 64 tile everywhere
  *                       (TRX_GEMM_BIG)                                                                              auto: on
  *   LU (trx_lu_solve, trx_inverse and everything built on them)
- *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain; 0 = 1024, 1 = never
+ *   "lu_split"    rows: a panel is factored by several workgroups per matrix while at least this many rows remain (TRX_LU_SPLIT); 1 = never;
+ *                       0 = automatic: only panels too tall for the LDS-resident one-workgroup kernel (fp64: above 1971 rows, fp32: 3942)
  *   "lu_split_batch"  largest batch that uses the row-split panel (TRX_LU_SPLIT_BATCH); 0 = any batch
- *   "lu_sub"      1 = panels column by column as in rounds 1 - 5 (TRX_LU_SUB)         auto: sub-blocks of 8 columns (same pivots)
+ *   "lu_sub"      1 = panels column by column as in rounds 1 - 5, 2 = sub-blocks of 4 columns everywhere (TRX_LU_SUB)
+ *                       auto: sub-blocks of 8 columns, of 4 for panels too tall for 8 (same pivots)
  *   Hessenberg reduction
  *   "hess_group"  1-4   panels whose right updates of Z and of the rows above the panel are merged into one block reflector and applied
  *                       together (TRX_HESS_GROUP); 1 = every panel on its own as in rounds 1 - 5                      auto: 4

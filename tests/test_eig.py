@@ -187,29 +187,6 @@ def test_eig_hessenberg_delayed_right_updates(backend, group):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("batch", [3, 2])
-def test_eig_hessenberg_paired_launches(backend, batch):
-    """Column loop of the Hessenberg reduction as paired launches (eig_hess.hip: hess_pair_kernel -- one launch streams for one half of the
-    batch and runs the reflector step of the other half; automatic from batch 24, forced here): an odd batch (halves of 2 and 1), both
-    precisions, a ragged last panel; same eigenpairs as the two-kernel form to the solver's accuracy class."""
-    if backend == "emu" and batch == 2:
-        pytest.skip("emulator time budget: the odd batch covers both halves and the unequal split")
-    be = get_backend(backend)
-    n = 107 if backend == "emu" else 333
-    rng = np.random.default_rng(50 + batch)
-    A = (rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))).astype(np.complex128)
-    A[-1] = 0.3 * A[-1] + np.diag(np.linspace(-5, 5, n)).astype(np.complex128)
-    try:
-        _set_knobs(be, hess_pair=2, eig_vec=1)
-        w, V, info = run_eig(be, A)
-        w32, V32, info32 = run_eig(be, A.astype(np.complex64))
-    finally:
-        _set_knobs(be, hess_pair=0, eig_vec=0)
-    check(A, w, V, info, 1e-13)
-    check(A.astype(np.complex64), w32, V32, info32, 5e-6)
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("knobs", [dict(qr_super=4), dict(qr_super=8, slab_spw=2), dict(qr_super=1), dict(qr_super=3, slab_band=1), dict(qr_super=4, qr_fuse=1)])
 def test_eig_super_steps_fp32(backend, knobs):
     """fp32 QR phase (first stage of the mixed-precision route; complex64 problems under precision="native"): a launch of the window kernel

@@ -31,13 +31,15 @@ constexpr int HRG = HCT / HNB;      // row groups of its HNB x HRG thread grid
 //   hess_col_kernel(c)   one workgroup per matrix:  w = T^H (sum of the partials);  b = Bcol - V w  (one pass, b kept in LDS);  one combined
 //                        reduction for |b[j+2:]|^2 and u = V[j+2:,:]^H b;  reflector;  write-back pass;  t_c = conj(V[j+1,:]) + scale u;  T[:,c].
 template <class T>
-__device__ __forceinline__ void hess_col_body(char* smem, int b, cx<T>* Aall, int n, int p0, int c, int nwg,
-                                              cx<T>* __restrict__ Vall, cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all,
-                                              cx<T>* __restrict__ tvec_all, const cx<T>* __restrict__ Bcol_all, const cx<T>* __restrict__ wpart_all) {
+__global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int c, int nwg,
+                                                        cx<T>* __restrict__ Vall, cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all,
+                                                        cx<T>* __restrict__ tvec_all, const cx<T>* __restrict__ Bcol_all, const cx<T>* __restrict__ wpart_all) {
+    TRX_DYN_SMEM(smem);
     cx<T>* bcol = reinterpret_cast<cx<T>*>(smem);     // [n]   current column (rows p0+1..n-1 at index r-(p0+1))
     cx<T>* part = bcol + n;                            // [HRG][HNB] partial sums
     cx<T>* vec = part + HRG * HNB;                     // [HNB]  w, then u
     T* red = reinterpret_cast<T*>(vec + HNB);          // [16] scalar reduction scratch
+    const int b = blockIdx.x;
     cx<T>* A = Aall + (long)b * n * n;
     cx<T>* V = Vall + (long)b * n * HNB;
     cx<T>* Tm = Tall + (long)b * HNB * HNB;
@@ -141,25 +143,20 @@ __device__ __forceinline__ void hess_col_body(char* smem, int b, cx<T>* Aall, in
     }
     for (int r = t; r < r0; r += blockDim.x) V[(long)r * HNB + c] = cx<T>(T(0), T(0));
 }
-template <class T>
-__global__ __launch_bounds__(HCT) void hess_col_kernel(cx<T>* __restrict__ Aall, int n, int p0, int c, int nwg,
-                                                        cx<T>* __restrict__ Vall, cx<T>* __restrict__ Tall, cx<T>* __restrict__ tau_all,
-                                                        cx<T>* __restrict__ tvec_all, const cx<T>* __restrict__ Bcol_all, const cx<T>* __restrict__ wpart_all) {
-    TRX_DYN_SMEM(smem);
-    hess_col_body<T>(reinterpret_cast<char*>(smem), blockIdx.x, Aall, n, p0, c, nwg, Vall, Tall, tau_all, tvec_all, Bcol_all, wpart_all);
-}
 
 // Wide launch of column c.  RPW rows per wave and pass: the v element read from LDS serves all of them, and RPW row loads per lane are in
 // flight (2: 5.07 TB/s in situ at the bench shape; 4: +0.7 % / +2.7 % of the whole step at batch 128 / 16).  The row-local tail (Y final,
 // next column's b, partial V^H b) handles two rows at a time on the two halves of the wave (lane & 31 = panel column q).
 template <class T, int RPW>
-__device__ __forceinline__ void hess_gemv_body(char* smem, int b, int bx, int nbx, const cx<T>* Aall, int n, int r0, int j, int c, int next,
-                                               const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, const cx<T>* __restrict__ tau_all,
-                                               const cx<T>* __restrict__ tvec_all, cx<T>* __restrict__ Bcol_all, cx<T>* __restrict__ wpart_all,
-                                               int rows_per_block) {
+__global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c, int next,
+                                                         const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, const cx<T>* __restrict__ tau_all,
+                                                         const cx<T>* __restrict__ tvec_all, cx<T>* __restrict__ Bcol_all, cx<T>* __restrict__ wpart_all,
+                                                         int rows_per_block) {
+    TRX_DYN_SMEM(smem);
     static_assert(RPW % 2 == 0 && HNB == 32, "two rows per half-wave round");
     cx<T>* v = reinterpret_cast<cx<T>*>(smem);        // [n - j - 1]
     cx<T>* wred = v + (n - j - 1);                     // [waves][HNB] partial V^H b of each wave
+    const int b = blockIdx.y;
     const cx<T>* A = Aall + (long)b * n * n;
     const cx<T>* V = Vall + (long)b * n * HNB;
     cx<T>* Y = Yall + (long)b * n * HNB;
@@ -168,7 +165,7 @@ __device__ __forceinline__ void hess_gemv_body(char* smem, int b, int bx, int nb
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int q = lane & 31, half = lane >> 5;
-    const int rbeg = r0 + bx * rows_per_block;
+    const int rbeg = r0 + blockIdx.x * rows_per_block;
     const cx<T> tau_c = tau_all[(long)b * HNB + c];
     const cx<T> tq = (q < c) ? tvec_all[(long)b * HNB + q] : cx<T>(T(0), T(0));
     const cx<T> vjn = (next && q <= c) ? conj(V[(long)(j + 1) * HNB + q]) : cx<T>(T(0), T(0));       // conj(V[j+1, q]); V[j+1, c] = 1
@@ -249,37 +246,8 @@ __device__ __forceinline__ void hess_gemv_body(char* smem, int b, int bx, int nb
         if (threadIdx.x < HNB) {
             cx<T> sW(T(0), T(0));
             for (int w = 0; w < nw; ++w) sW += wred[w * HNB + threadIdx.x];
-            wpart_all[((long)b * nbx + bx) * HNB + threadIdx.x] = sW;
+            wpart_all[((long)b * gridDim.x + blockIdx.x) * HNB + threadIdx.x] = sW;
         }
-    }
-}
-template <class T, int RPW>
-__global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict__ Aall, int n, int r0, int j, int c, int next,
-                                                         const cx<T>* __restrict__ Vall, cx<T>* __restrict__ Yall, const cx<T>* __restrict__ tau_all,
-                                                         const cx<T>* __restrict__ tvec_all, cx<T>* __restrict__ Bcol_all, cx<T>* __restrict__ wpart_all,
-                                                         int rows_per_block) {
-    TRX_DYN_SMEM(smem);
-    hess_gemv_body<T, RPW>(reinterpret_cast<char*>(smem), blockIdx.y, blockIdx.x, gridDim.x, Aall, n, r0, j, c, next, Vall, Yall, tau_all, tvec_all, Bcol_all,
-                           wpart_all, rows_per_block);
-}
-
-// Paired launch (round 6): the batch is cut into two halves that run half a column step out of phase, and ONE launch carries the wide BLAS-2
-// stream of one half (workgroups 1 .. nwg of a matrix row of the grid) and the reflector step of the other half (workgroup 0) -- the one-
-// workgroup-per-matrix reflector kernel is 33 us of LDS round trips and barriers per column during which the chip was otherwise idle (72 ms of
-// a 128-point step); it now runs under the other half's stream.  Same kernels' code, same launch count, no second stream.
-// gemv role: matrices [gm0, gm0 + gcount), panel column gc (< 0: none); reflector role: matrices [cm0, cm0 + ccount), panel column cc (< 0: none).
-template <class T, int RPW>
-__global__ __launch_bounds__(512) void hess_pair_kernel(cx<T>* Aall, int n, int p0, int nwg, int rows_per_block, cx<T>* Vall, cx<T>* Yall, cx<T>* Tall,
-                                                         cx<T>* tau_all, cx<T>* tvec_all, cx<T>* Bcol_all, cx<T>* wpart_all,
-                                                         int gm0, int gcount, int gc, int gnext, int cm0, int ccount, int cc) {
-    TRX_DYN_SMEM(smem);
-    if (blockIdx.x == 0) {
-        if (cc >= 0 && (int)blockIdx.y < ccount)
-            hess_col_body<T>(reinterpret_cast<char*>(smem), cm0 + blockIdx.y, Aall, n, p0, cc, nwg, Vall, Tall, tau_all, tvec_all, (const cx<T>*)Bcol_all, (const cx<T>*)wpart_all);
-    } else {
-        if (gc >= 0 && (int)blockIdx.y < gcount)
-            hess_gemv_body<T, RPW>(reinterpret_cast<char*>(smem), gm0 + blockIdx.y, blockIdx.x - 1, nwg, (const cx<T>*)Aall, n, p0 + 1, p0 + gc, gc, gnext, (const cx<T>*)Vall, Yall,
-                                   (const cx<T>*)tau_all, (const cx<T>*)tvec_all, Bcol_all, wpart_all, rows_per_block);
     }
 }
 
@@ -343,14 +311,10 @@ static int hess_rpw(int batch) {
 // rounds 1 - 5.
 static int hess_group_env() { const char* e = getenv("TRX_HESS_GROUP"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= EigPlan::HG) ? v : 0; }
 static int g_hess_group = hess_group_env();
-// Paired launches of the column loop (hess_pair_kernel): TRX_HESS_PAIR / trx_tuning("hess_pair", v): 0 automatic (batch >= 24), 1 = off, 2 = always
-static int hess_pair_env() { const char* e = getenv("TRX_HESS_PAIR"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }
-static int g_hess_pair = hess_pair_env();
 int hess_set_knob(const char* key, int value) {
-    const std::string k(key);
-    if (k == "hess_group") { if (value < 0 || value > EigPlan::HG) return TRX_ERR_ARG; g_hess_group = value; return TRX_OK; }
-    if (k == "hess_pair") { if (value < 0 || value > 2) return TRX_ERR_ARG; g_hess_pair = value; return TRX_OK; }
-    return TRX_ERR_ARG;
+    if (std::string(key) != "hess_group" || value < 0 || value > EigPlan::HG) return TRX_ERR_ARG;
+    g_hess_group = value;
+    return TRX_OK;
 }
 
 // The right updates of a panel's block reflector touch two regions that never feed back into the reduction: the rows of A above the panel and
@@ -395,6 +359,10 @@ static int hess_flush_group(hipStream_t s, const EigBuffers<T>& B, int n, int ba
     return TRX_OK;
 }
 
+// (Paired launches -- the batch in two halves half a column step apart, ONE launch streaming for one half and running the reflector step of
+// the other, no second stream -- were built and measured in round 6: the reflector kernel does hide (its tag disappears), but a launch that
+// streams half the batch takes 170 us where the full batch takes 295, and the phase stays at 881 - 887 ms (batch 32: 279 -> 296 ms).
+// Removed; profiles/r06_ab/r6t_hessenberg_paired_launches.txt.)
 // (Two to four sub-batches on side streams, half a panel out of phase -- one's block updates and reflector kernels under the other's gemv
 // stream -- were measured in round 6 and removed: the phase takes 882 ms as one batch of 128 and 914 / 946 / 1001 ms as 2 / 3 / 4 sub-batches;
 // two chip-filling gemv grids share the chip instead of overlapping.  profiles/r06_ab/cumask.txt)
@@ -406,10 +374,8 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     TRX_LAUNCH((set_identity_batched<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, Z, n);
     const size_t sm_col = sizeof(cx<T>) * ((size_t)n + HRG * HNB + HNB) + sizeof(T) * 16;
     const size_t sm_gemv = sizeof(cx<T>) * ((size_t)n + 8 * HNB);
-    const size_t sm_pair = sm_col > sm_gemv ? sm_col : sm_gemv;
     if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sm_gemv) ||
-        set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv) || set_max_dyn_smem((const void*)hess_pair_kernel<T, 2>, sm_pair) ||
-        set_max_dyn_smem((const void*)hess_pair_kernel<T, 4>, sm_pair))
+        set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv))
         return TRX_ERR_LAUNCH;
     const int rpw = hess_rpw(batch);
     cx<T>* Bcol = W;            // [B, n]        next column with the pending right update applied (the GEMM scratch is free during the column loop)
@@ -426,28 +392,6 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
         const bool few = (long)cdiv_i(nr, 64) * batch < 256;
         const int rpb = few ? 16 : 64, gthreads = few ? 512 : 256;
         const int nwg = cdiv_i(nr, rpb);
-        const bool pair = !few && batch >= 2 && (g_hess_pair == 2 || (g_hess_pair == 0 && batch >= 24));
-        if (pair) {
-            // two halves of the batch half a column step apart: every launch streams for one half and runs the reflector step of the other
-            const int hA = (batch + 1) / 2, hB = batch - hA;
-            const int nwp = cdiv_i(nr, 64);                    // 64 rows per 8-wave workgroup of the stream role
-            const dim3 grid(1 + nwp, hA);
-            auto launch = [&](int gm0, int gcount, int gc, int cm0, int ccount, int cc) {
-                const int gnext = (gc >= 0 && gc + 1 < ib) ? 1 : 0;
-                const double rows = gc >= 0 ? (double)nr * (n - (p0 + gc) - 1) * gcount : 0.0;
-                ProfScope prof(PROF_HESS_GEMV, s, 8.0 * rows, (double)sizeof(cx<T>) * rows);
-                if (rpw == 4)
-                    TRX_LAUNCH((hess_pair_kernel<T, 4>), grid, dim3(512), sm_pair, s, A, n, p0, nwp, 64, V, Y, Tm, B.tau, B.tvec, Bcol, wpart, gm0, gcount, gc, gnext, cm0, ccount, cc);
-                else
-                    TRX_LAUNCH((hess_pair_kernel<T, 2>), grid, dim3(512), sm_pair, s, A, n, p0, nwp, 64, V, Y, Tm, B.tau, B.tvec, Bcol, wpart, gm0, gcount, gc, gnext, cm0, ccount, cc);
-                return 0;
-            };
-            launch(0, 0, -1, 0, hA, 0);                                         // reflector of column 0, first half
-            for (int c = 0; c < ib; ++c) {
-                launch(0, hA, c, hA, hB, c);                                    // stream of the first half | reflector of the second
-                launch(hA, hB, c, 0, hA, c + 1 < ib ? c + 1 : -1);              // stream of the second half | next reflector of the first
-            }
-        } else
         for (int c = 0; c < ib; ++c) {
             const int j = p0 + c;
             { ProfScope prof(PROF_HESS_COL, s, 0, 0);
