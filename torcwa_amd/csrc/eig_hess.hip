@@ -155,13 +155,18 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
     TRX_DYN_SMEM(smem);
     static_assert(RPW % 2 == 0 && HNB == 32, "two rows per half-wave round");
     cx<T>* v = reinterpret_cast<cx<T>*>(smem);        // [n - j - 1]
-    cx<T>* wred = v + (n - j - 1);                     // [waves][HNB] partial V^H b of each wave
+    cx<T>* wred = v + (n - j - 1) + 2;                 // [waves][HNB] partial V^H b of each wave (v may sit one element in: see `off`)
     const int b = blockIdx.y;
     const cx<T>* A = Aall + (long)b * n * n;
     const cx<T>* V = Vall + (long)b * n * HNB;
     cx<T>* Y = Yall + (long)b * n * HNB;
     const int len = n - j - 1;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) v[i] = V[(long)(j + 1 + i) * HNB + c];
+    // fp32, even n: the row stream is read as PAIRS of elements (16 bytes per lane, like the fp64 stream) -- every row of A starts at an even
+    // element index when n is even, so the pairs i = off, off + 2, ... with off = (j + 1) & 1 are 16-byte aligned in every row; v sits in LDS
+    // shifted by off so that its pairs are aligned too.  (8-byte loads kept the fp32 stream at 4.3 TB/s in situ where the fp64 one reaches 5.2.)
+    const bool pairs = sizeof(T) == 4 && (n & 1) == 0;
+    const int off = pairs ? ((j + 1) & 1) : 0;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) v[i + off] = V[(long)(j + 1 + i) * HNB + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int q = lane & 31, half = lane >> 5;
@@ -196,6 +201,46 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
         // load right behind it: ISA of round 3), half of what the fp64 stream has, and the fp32 gemv ran at 4.25 TB/s against 5.1 TB/s
         constexpr int UNR = sizeof(T) == 4 ? 2 : 1;
         int i = lane;
+        if (pairs) {
+            if constexpr (sizeof(T) == 4) {
+                typedef float pair_t __attribute__((ext_vector_type(4)));          // two complex elements
+                const int npair = (len - off) >> 1;
+                const pair_t* vp = reinterpret_cast<const pair_t*>(v + 2 * off);   // pair p = elements off + 2 p, off + 2 p + 1; LDS slot 2 p + 2 off
+                int p = lane;
+                for (; p + 64 < npair; p += 128) {                                 // two 128-column chunks per round: 2 x RPW 16-byte loads in flight
+                    pair_t a0[RPW], a1[RPW];
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k) {
+                        const pair_t* rp = reinterpret_cast<const pair_t*>(row[k] + off);
+                        a0[k] = rp[p]; a1[k] = rp[p + 64];
+                    }
+                    const pair_t v0 = vp[p], v1 = vp[p + 64];
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k) {
+                        cfma(acc[k], cx<T>(a0[k].x, a0[k].y), cx<T>(v0.x, v0.y)); cfma(acc[k], cx<T>(a0[k].z, a0[k].w), cx<T>(v0.z, v0.w));
+                        cfma(acc[k], cx<T>(a1[k].x, a1[k].y), cx<T>(v1.x, v1.y)); cfma(acc[k], cx<T>(a1[k].z, a1[k].w), cx<T>(v1.z, v1.w));
+                    }
+                }
+                for (; p < npair; p += 64) {
+                    const pair_t v0 = vp[p];
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k) {
+                        const pair_t a0 = reinterpret_cast<const pair_t*>(row[k] + off)[p];
+                        cfma(acc[k], cx<T>(a0.x, a0.y), cx<T>(v0.x, v0.y)); cfma(acc[k], cx<T>(a0.z, a0.w), cx<T>(v0.z, v0.w));
+                    }
+                }
+                // the element in front of the first pair and the one behind the last
+                if (off && lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k) cfma(acc[k], row[k][0], v[off]);
+                }
+                if (((len - off) & 1) && lane == 1) {
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k) cfma(acc[k], row[k][len - 1], v[len - 1 + off]);
+                }
+            }
+            i = len;                                                               // nothing left for the element loops below
+        }
         for (; i + 64 * (UNR - 1) < len; i += 64 * UNR) {
             cx<T> a[UNR][RPW], vi[UNR];
 #pragma unroll
@@ -203,14 +248,14 @@ __global__ __launch_bounds__(512) void hess_gemv_kernel(const cx<T>* __restrict_
 #pragma unroll
                 for (int k = 0; k < RPW; ++k) a[u][k] = row[k][i + 64 * u];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) vi[u] = v[i + 64 * u];
+            for (int u = 0; u < UNR; ++u) vi[u] = v[i + 64 * u + off];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
                 for (int k = 0; k < RPW; ++k) cfma(acc[k], a[u][k], vi[u]);
         }
         for (; i < len; i += 64) {
-            const cx<T> vi = v[i];
+            const cx<T> vi = v[i + off];
 #pragma unroll
             for (int k = 0; k < RPW; ++k) cfma(acc[k], row[k][i], vi);
         }
@@ -373,7 +418,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     cx<T>*A = B.A, *Z = B.Z, *V = B.Vp, *Y = B.Yp, *Tm = B.Tp, *W = B.W1, *W2 = B.W2;
     TRX_LAUNCH((set_identity_batched<T>), dim3(cdiv_i(n, 256), n, batch), dim3(256), 0, s, Z, n);
     const size_t sm_col = sizeof(cx<T>) * ((size_t)n + HRG * HNB + HNB) + sizeof(T) * 16;
-    const size_t sm_gemv = sizeof(cx<T>) * ((size_t)n + 8 * HNB);
+    const size_t sm_gemv = sizeof(cx<T>) * ((size_t)n + 2 + 8 * HNB);
     if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sm_gemv) ||
         set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv))
         return TRX_ERR_LAUNCH;
@@ -397,7 +442,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
             { ProfScope prof(PROF_HESS_COL, s, 0, 0);
               TRX_LAUNCH((hess_col_kernel<T>), dim3(batch), dim3(HCT), sm_col, s, A, n, p0, c, nwg, V, Tm, B.tau, B.tvec, (const cx<T>*)Bcol, (const cx<T>*)wpart); }
             const int next = (c + 1 < ib) ? 1 : 0;
-            const size_t smg = sizeof(cx<T>) * ((size_t)(n - j - 1) + (gthreads / 64) * HNB);
+            const size_t smg = sizeof(cx<T>) * ((size_t)(n - j - 1) + 2 + (gthreads / 64) * HNB);
             // algorithmic traffic of the BLAS-2 stream: the (n-r0) x (n-j-1) trailing block is read once per matrix
             ProfScope prof(PROF_HESS_GEMV, s, 8.0 * (double)nr * (n - j - 1) * batch, (double)sizeof(cx<T>) * nr * (double)(n - j - 1) * batch);
             if (rpw == 4 && !few)
