@@ -347,11 +347,11 @@ __global__ __launch_bounds__(256) void set_identity_batched(cx<T>* __restrict__ 
 
 // rows per wave and pass of the wide launch (TRX_HESS_RPW = 2 / 4 forces one).  Measured with the fused row-local tail (whole step, round 3):
 // batch 128: 2 rows 29.47-29.73, 4 rows 29.22-29.45 layer-solves/s;  batch 16: 2 rows 13.37, 4 rows 13.64
-// Round 6, fp32 stream read as 16-byte pairs (even n): 4 rows at every batch size (batch 128: stream 538 against 547 ms per step with 2 rows;
-// profiles/r06_ab/r6u_fp32_stream_16_byte_loads.txt).
-static int hess_rpw(int batch, bool fp32_pairs) {
+// Round 6, fp32 stream read as 16-byte pairs: 2 against 4 rows at batch 128 measured twice, 36.60 / 36.66 / 36.88 against 36.76 / 36.61
+// layer-solves/s -- no difference, the rule stands (profiles/r06_ab/r6u..., r6v...).
+static int hess_rpw(int batch) {
     static const int v = [] { const char* e = getenv("TRX_HESS_RPW"); const int x = e ? atoi(e) : 0; return (x == 2 || x == 4) ? x : 0; }();
-    return v ? v : ((batch >= 64 && !fp32_pairs) ? 2 : 4);
+    return v ? v : (batch >= 64 ? 2 : 4);
 }
 
 // Panels per group of the delayed right updates (TRX_HESS_GROUP / trx_tuning("hess_group", g)): 0 automatic (4), 1 = every panel on its own as in
@@ -424,7 +424,7 @@ int hessenberg(hipStream_t s, const EigBuffers<T>& B, int n, int batch) {
     if (set_max_dyn_smem((const void*)hess_col_kernel<T>, sm_col) || set_max_dyn_smem((const void*)hess_gemv_kernel<T, 2>, sm_gemv) ||
         set_max_dyn_smem((const void*)hess_gemv_kernel<T, 4>, sm_gemv))
         return TRX_ERR_LAUNCH;
-    const int rpw = hess_rpw(batch, sizeof(T) == 4 && (n & 1) == 0);
+    const int rpw = hess_rpw(batch);
     cx<T>* Bcol = W;            // [B, n]        next column with the pending right update applied (the GEMM scratch is free during the column loop)
     cx<T>* wpart = W2;          // [B, nwg, HNB] partial sums of V^H b, one row per workgroup of the wide launch
     const int hg = g_hess_group ? g_hess_group : EigPlan::HG;        // panels per group of the delayed right updates (1: none delayed)
