@@ -195,5 +195,8 @@ int gemm_set_knob(const char* key, int value);        // trx_tuning("gemm_big", 
 template <class T>
 int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB,
              int nrhs, int batch);
+// X = B A^-1 in place on B [nrows x n] from the factors of lu_factor; idx: n ints per matrix of scratch (lu.hip)
+template <class T>
+int lu_solve_right(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB, int nrows, int batch, int* idx);
 
 }  // namespace trx

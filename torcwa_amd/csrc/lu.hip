@@ -676,6 +676,92 @@ __global__ __launch_bounds__(256) void trsm_kernel(const cx<T>* __restrict__ Tal
         if (i < jb) B[(long)i * ldb + c] = x[i];
 }
 
+// X = B U^-1 (non-unit upper, UPPER) or X = B L^-1 (UNIT lower) for the jb x jb triangle at Tm: B is nrows x jb, in place; one thread per ROW
+// (a row's jb elements are contiguous: each lane reads and writes whole cache lines of its own).
+template <class T, bool UPPER>
+__global__ __launch_bounds__(256) void trsm_right_kernel(const cx<T>* __restrict__ Tall, int ldt, long sT, int jb,
+                                                         cx<T>* __restrict__ Ball, int ldb, long sB, int nrows) {
+    __shared__ cx<T> Ts[NB][NB + 1];
+    const int b = blockIdx.y;
+    const cx<T>* Tm = Tall + (long)b * sT;
+    cx<T>* B = Ball + (long)b * sB;
+    for (int e = threadIdx.x; e < jb * jb; e += blockDim.x) {
+        const int r = e / jb, c = e % jb;
+        cx<T> v = Tm[(long)r * ldt + c];
+        if (UPPER && r == c) v = crecip(v);
+        Ts[r][c] = v;
+    }
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    cx<T>* row = B + (long)r * ldb;
+    cx<T> x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = (i < jb) ? row[i] : cx<T>(T(0), T(0));
+    if (UPPER) {                 // x U = b: columns ascending, x_j = (b_j - sum_{i<j} x_i U_ij) / U_jj
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < jb) {
+                cx<T> sacc = x[j];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (i < j) cfma(sacc, -Ts[i][j], x[i]);
+                x[j] = sacc * Ts[j][j];
+            }
+        }
+    } else {                     // x L = b, unit diagonal: columns descending, x_j = b_j - sum_{i>j} x_i L_ij
+#pragma unroll
+        for (int j = NB - 1; j >= 0; --j) {
+            if (j < jb) {
+                cx<T> sacc = x[j];
+#pragma unroll
+                for (int i = NB - 1; i >= 0; --i)
+                    if (i > j && i < jb) cfma(sacc, -Ts[i][j], x[i]);
+                x[j] = sacc;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (i < jb) row[i] = x[i];
+}
+
+// idx[c] = the column of Z that ends up in column c of X = Z P (P = P_{n-1} ... P_0, the row interchanges of P A = L U): the column swaps
+// (k, piv[k]) applied for k = n-1 down to 0 to the identity.  One thread per matrix, the index array in LDS.
+__global__ __launch_bounds__(64) void perm_compose_kernel(const int* __restrict__ piv_all, int n, int* __restrict__ idx_all) {
+    TRX_DYN_SMEM(smem);
+    int* idx = reinterpret_cast<int*>(smem);
+    const int b = blockIdx.x;
+    const int* piv = piv_all + (long)b * n;
+    for (int c = threadIdx.x; c < n; c += 64) idx[c] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = n - 1; k >= 0; --k) {
+            const int p = piv[k];
+            if (p != k) { const int a = idx[k]; idx[k] = idx[p]; idx[p] = a; }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += 64) idx_all[(long)b * n + c] = idx[c];
+}
+
+// X[r, c] = Z[r, idx[c]] in place: a workgroup takes rows one at a time through LDS (coalesced both ways, the gather happens in LDS)
+template <class T>
+__global__ __launch_bounds__(256) void col_permute_kernel(cx<T>* __restrict__ Ball, int ldb, long sB, int nrows, int n, const int* __restrict__ idx_all, int rows_per_block) {
+    TRX_DYN_SMEM(smem);
+    cx<T>* rowbuf = reinterpret_cast<cx<T>*>(smem);            // [n]
+    const int b = blockIdx.y;
+    cx<T>* B = Ball + (long)b * sB;
+    const int* idx = idx_all + (long)b * n;
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int r = r0; r < r0 + rows_per_block && r < nrows; ++r) {
+        cx<T>* row = B + (long)r * ldb;
+        for (int c = threadIdx.x; c < n; c += blockDim.x) rowbuf[c] = row[c];
+        __syncthreads();
+        for (int c = threadIdx.x; c < n; c += blockDim.x) row[c] = rowbuf[idx[c]];
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // Two-level blocking: panels of NB columns are factored one at a time, but the update of everything to the right of
@@ -876,9 +962,67 @@ int lu_solve(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int*
     return TRX_OK;
 }
 
+// Right-sided counterpart of tri_block_solve: X U = B / X L = B on the COLUMNS [r0, r1) of B (nrows rows), by the same recursive halving.
+template <class T, bool UPPER>
+static int tri_block_solve_right(hipStream_t s, const cx<T>* LU, int lda, long sA, int r0, int r1, cx<T>* B, int ldb, long sB, int nrows, int batch) {
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
+    const int m = r1 - r0;
+    if (m <= 0) return TRX_OK;
+    if (m <= NB) {
+        TRX_LAUNCH((trsm_right_kernel<T, UPPER>), dim3(cdiv_i(nrows, 256), batch), dim3(256), 0, s, LU + (long)r0 * lda + r0, lda, sA, m, B + r0, ldb, sB, nrows);
+        return TRX_OK;
+    }
+    int h = NB;
+    while (2 * h < m) h *= 2;
+    const int mid = r0 + h;
+    int rc;
+    if (UPPER) {       // columns ascending: X[:, mid:r1] needs X[:, r0:mid] U[r0:mid, mid:r1]
+        if ((rc = tri_block_solve_right<T, true>(s, LU, lda, sA, r0, mid, B, ldb, sB, nrows, batch))) return rc;
+        if ((rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nrows, r1 - mid, h, mone, B + r0, ldb, sB, LU + (long)r0 * lda + mid, lda, sA, one, B + mid, ldb, sB, batch))) return rc;
+        return tri_block_solve_right<T, true>(s, LU, lda, sA, mid, r1, B, ldb, sB, nrows, batch);
+    }
+    // columns descending: X[:, r0:mid] needs X[:, mid:r1] L[mid:r1, r0:mid]
+    if ((rc = tri_block_solve_right<T, false>(s, LU, lda, sA, mid, r1, B, ldb, sB, nrows, batch))) return rc;
+    if ((rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nrows, h, r1 - mid, mone, B + mid, ldb, sB, LU + (long)mid * lda + r0, lda, sA, one, B + r0, ldb, sB, batch))) return rc;
+    return tri_block_solve_right<T, false>(s, LU, lda, sA, r0, mid, B, ldb, sB, nrows, batch);
+}
+
+// X = B A^-1 from the factors of P A = L U (lu_factor), in place on B [nrows x n]:  X = B U^-1 L^-1 P.  idx: n ints per matrix of scratch.
+// Replaces the transposed-system route of rounds 1 - 5 (A^T factored, B^T solved from the left, the result transposed back: three tiled
+// transposes per right solve); same blocking as lu_solve with rows and columns exchanged.
+template <class T>
+int lu_solve_right(hipStream_t s, const cx<T>* LU, int lda, long sA, int n, const int* piv, cx<T>* B, int ldb, long sB, int nrows, int batch, int* idx) {
+    if (n <= 0 || nrows <= 0 || batch <= 0) return TRX_OK;
+    const cx<T> one(T(1), T(0)), mone(T(-1), T(0));
+    int rc;
+    for (int K0 = 0; K0 < n; K0 += NBO) {            // Y U = B: column blocks ascending
+        const int kb = (n - K0 < NBO) ? (n - K0) : NBO, Kend = K0 + kb;
+        if ((rc = tri_block_solve_right<T, true>(s, LU, lda, sA, K0, Kend, B, ldb, sB, nrows, batch))) return rc;
+        if (n - Kend > 0 &&
+            (rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nrows, n - Kend, kb, mone, B + K0, ldb, sB, LU + (long)K0 * lda + Kend, lda, sA, one, B + Kend, ldb, sB, batch))) return rc;
+    }
+    const int lastK = ((n - 1) / NBO) * NBO;
+    for (int K0 = lastK; K0 >= 0; K0 -= NBO) {       // Z L = Y: column blocks descending
+        const int kb = (n - K0 < NBO) ? (n - K0) : NBO, Kend = K0 + kb;
+        if ((rc = tri_block_solve_right<T, false>(s, LU, lda, sA, K0, Kend, B, ldb, sB, nrows, batch))) return rc;
+        if (K0 > 0 &&
+            (rc = gemm<T>(s, TRX_OP_N, TRX_OP_N, nrows, K0, kb, mone, B + K0, ldb, sB, LU + (long)K0 * lda, lda, sA, one, B, ldb, sB, batch))) return rc;
+    }
+    // X = Z P
+    const size_t smi = sizeof(int) * (size_t)n, smr = sizeof(cx<T>) * (size_t)n;
+    if (set_max_dyn_smem((const void*)perm_compose_kernel, smi) || set_max_dyn_smem((const void*)col_permute_kernel<T>, smr)) return TRX_ERR_LAUNCH;
+    TRX_LAUNCH(perm_compose_kernel, dim3(batch), dim3(64), smi, s, piv, n, idx);
+    const int rpb = 4;
+    TRX_LAUNCH((col_permute_kernel<T>), dim3(cdiv_i(nrows, rpb), batch), dim3(256), smr, s, B, ldb, sB, nrows, n, (const int*)idx, rpb);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 template int lu_factor<float>(hipStream_t, cx<float>*, int, long, int, int*, int, int*);
 template int lu_factor<double>(hipStream_t, cx<double>*, int, long, int, int*, int, int*);
 template int lu_solve<float>(hipStream_t, const cx<float>*, int, long, int, const int*, cx<float>*, int, long, int, int);
 template int lu_solve<double>(hipStream_t, const cx<double>*, int, long, int, const int*, cx<double>*, int, long, int, int);
+template int lu_solve_right<float>(hipStream_t, const cx<float>*, int, long, int, const int*, cx<float>*, int, long, int, int, int*);
+template int lu_solve_right<double>(hipStream_t, const cx<double>*, int, long, int, const int*, cx<double>*, int, long, int, int, int*);
 
 }  // namespace trx

@@ -267,16 +267,13 @@ int layer_smatrix_t(hipStream_t s, const cx<T>* P, const cx<T>* Q, const cx<T>* 
     int* piv2 = piv + (long)batch * n;               // caller provides 3*batch*n ints
     int* info2 = info + batch;                       // and 3*batch info slots
     if (!cp) {
-        // Coupling coefficients not requested: M+ = W(I+X) Tp^-1 and M- = W(I-X) Tm^-1 are RIGHT solves.  Done as left
-        // solves of the transposed systems (Tp^T M+^T = (W(I+X))^T): three O(n^2) tiled transposes replace the solve
-        // against the identity and both n^3 products of the explicit-inverse route (2.67 n^3 instead of 4.67 n^3 cMAC).
-        const dim3 tg(cdiv_i(n, TRC), cdiv_i(n, TRR), 2 * batch), tb(32, 8);
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, n, nn, G, n, nn, n);                         // G  = Tp^T | Tm^T
+        // Coupling coefficients not requested: M+ = W(I+X) Tp^-1 and M- = W(I-X) Tm^-1 are RIGHT solves, done as such from the factors of
+        // Tp | Tm (lu_solve_right: X U = B, then X L = ., then the column permutation) -- 2.67 n^3 instead of the 4.67 n^3 cMAC of the
+        // explicit-inverse route.  (Rounds 1 - 5 solved the transposed systems from the left: three tiled transposes of [2B,n,n] per call,
+        // 20 ms of a 128-point step.)
         TRX_LAUNCH((layer_R_kernel<T>), g, blk, 0, s, W, x, n, Mx, Mx + bn);                             // Mx = W(I+X) | W(I-X)
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)Mx, n, nn, T2, n, nn, n);                        // T2 = R+^T | R-^T
-        rc = lu_factor<T>(s, G, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
-        rc = lu_solve<T>(s, G, n, nn, n, piv2, T2, n, nn, n, 2 * batch); if (rc) return rc;              // T2 = M+^T | M-^T
-        TRX_LAUNCH((transpose_kernel<T>), tg, tb, 0, s, (const cx<T>*)T2, n, nn, Mx, n, nn, n);                        // Mx = M+ | M-
+        rc = lu_factor<T>(s, T2, n, nn, n, piv2, 2 * batch, info2); if (rc) return rc;
+        rc = lu_solve_right<T>(s, T2, n, nn, n, piv2, Mx, n, nn, n, 2 * batch, reinterpret_cast<int*>(G)); if (rc) return rc;     // Mx = M+ | M-
         TRX_LAUNCH((layer_S_kernel<T>), g, blk, 0, s, (const cx<T>*)Mx, (const cx<T>*)(Mx + bn), n, S11, S21);
         TRX_CHECK_LAUNCH();
         return TRX_OK;
