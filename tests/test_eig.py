@@ -173,17 +173,20 @@ def test_eig_hessenberg_delayed_right_updates(backend, group):
     if backend == "emu" and group in (2, 4):
         pytest.skip("emulator time budget: 4 is the default of every other emulator test, 3 covers the asymmetric merge")
     be = get_backend(backend)
-    n = 171 if backend == "emu" else 333          # 171: panels at 0, 32, ..., 160 (6, the last with 9 columns); 333: 11 panels
+    n = 139 if backend == "emu" else 333          # 139: panels at 0, 32, ..., 128 (5, the last with 9 columns); 333: 11 panels
     A = (RNG.standard_normal((2, n, n)) + 1j * RNG.standard_normal((2, n, n))).astype(np.complex128)
     A[1] = 0.3 * A[1] + np.diag(np.linspace(-5, 5, n)).astype(np.complex128)
     try:
         _set_knobs(be, hess_group=group, eig_vec=1)
         w, V, info = run_eig(be, A)
-        w32, V32, info32 = run_eig(be, A.astype(np.complex64))
+        fp32_too = backend != "emu" or group != 1      # emulator time budget: the per-panel form in one precision
+        if fp32_too:
+            w32, V32, info32 = run_eig(be, A.astype(np.complex64))
     finally:
         _set_knobs(be, hess_group=0, eig_vec=0)
     check(A, w, V, info, 1e-13)
-    check(A.astype(np.complex64), w32, V32, info32, 5e-6)
+    if fp32_too:
+        check(A.astype(np.complex64), w32, V32, info32, 5e-6)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
