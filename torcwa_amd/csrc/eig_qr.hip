@@ -1008,6 +1008,103 @@ __device__ __forceinline__ void band_left_strip(const T* __restrict__ Ur, const 
     }
 }
 
+// Right update of ONE 16-row strip by one wave, the mirror image of band_left_strip: rows a0 .. a0 + 15 of the columns w0 .. w0 + ww of X (H above
+// the window, or Z) times U.  The strip's 16 x 64 block sits in registers as the A operand (lane: row lr, k = 16 c + 4 lk + j), U comes from the
+// planes as the B operand, one 16 x 16 output tile at a time; a chase unitary has nonzero blocks only for k chunks <= q + 1 of column tile q.
+template <class T>
+__device__ __forceinline__ void band_right_strip(const T* __restrict__ Ur, const T* __restrict__ Ui, const SlabStrip<T>& d, int n, int w0, int ww, int lane, bool band) {
+    const int lr = lane & 15, lk = lane >> 4;
+    char* base = reinterpret_cast<char*>(d.X);
+    cx<T> x[16];
+    {
+        const int r = d.a0 + lr;
+        const int rc = r < d.lim ? r : d.lim - 1;
+        const unsigned p0 = ((unsigned)rc * n + w0) * (unsigned)sizeof(cx<T>);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * c + KLS * lk + j;
+                x[4 * c + j] = *reinterpret_cast<const cx<T>*>(base + (p0 + (unsigned)(k < ww ? k : ww - 1) * (unsigned)sizeof(cx<T>)));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        typename Mfma<T>::acc_t accR, accI;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accR[r] = T(0); accI[r] = T(0); }
+        const int cmax = band ? q + 1 : 3;
+        const T* ur = Ur + (KLS * lk) * MLD + lr + 16 * q;
+        const T* ui = Ui + (KLS * lk) * MLD + lr + 16 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > cmax) continue;                      // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T a = ur[(16 * c + j) * MLD], bq = ui[(16 * c + j) * MLD];
+                const cx<T> xv = x[4 * c + j];
+                // C = X U:    Cr += xr ur - xi ui,  Ci += xr ui + xi ur
+                accR = Mfma<T>::mma(xv.x, a, accR);
+                accI = Mfma<T>::mma(xv.x, bq, accI);
+                accR = Mfma<T>::mma(-xv.y, bq, accR);
+                accI = Mfma<T>::mma(xv.y, a, accI);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = d.a0 + Mfma<T>::crow(lane, r), col = 16 * q + lr;
+            if (row < d.lim && col < ww) *reinterpret_cast<cx<T>*>(base + ((unsigned)row * n + w0 + col) * (unsigned)sizeof(cx<T>)) = cx<T>(accR[r], accI[r]);
+        }
+    }
+}
+
+// Right / Z update of ONE chase link (several chains per sweep: one window step per launch) by the 16 waves of a workgroup of the window
+// kernel: U into the planes, then strips g0, g0 + 1, ... < g1 of the list [H rows 0 .. w0 in 16-row strips | Z rows 0 .. n], one per wave.
+template <class T>
+__device__ void right_link_strips(cx<T>* __restrict__ H, cx<T>* __restrict__ Z, int n, const QrLink& l, const cx<T>* __restrict__ U, T* Ur, T* Ui, int* vote,
+                                  int g0, int g1, int band_on, unsigned* __restrict__ work) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int UPT = QW * QW / WTHREADS;
+    const int kind = __builtin_amdgcn_readfirstlane(l.kind), w0 = __builtin_amdgcn_readfirstlane(l.w0), w1 = __builtin_amdgcn_readfirstlane(l.w1);
+    const int ww = w1 - w0;
+    if (kind != QRL_CHASE || ww <= 0) return;
+    const int nH = (w0 + 15) >> 4, nZ = (n + 15) >> 4;
+    const int lim = g1 < nH + nZ ? g1 : nH + nZ;
+    if (g0 >= lim) return;                                   // (workgroup-uniform)
+    cx<T> ureg[UPT];
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+        const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
+        ureg[q] = U[(k < ww ? k : ww - 1) * QW + (c < ww ? c : ww - 1)];
+    }
+    if (t == 0) vote[0] = 0;
+    __syncthreads();
+    int dense = 0;
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+        const int el = t + WTHREADS * q, k = el >> 6, c = el & 63;
+        cx<T> u = ureg[q];
+        if (k >= ww || c >= ww) u = cx<T>(T(0), T(0));
+        Ur[k * MLD + c] = u.x; Ui[k * MLD + c] = u.y;
+        if ((k >> 4) >= (c >> 4) + 2 && (u.x != T(0) || u.y != T(0))) dense = 1;
+    }
+    if (dense) vote[0] = 1;
+    __syncthreads();
+    const bool band = band_on && vote[0] == 0;
+    const int g = g0 + wave;
+    if (g < lim) {
+        SlabStrip<T> d;
+        d.side = 1;
+        if (g < nH) { d.X = H; d.a0 = 16 * g; d.lim = w0; }
+        else { d.X = Z; d.a0 = 16 * (g - nH); d.lim = n; }
+        band_right_strip<T>(Ur, Ui, d, n, w0, ww, lane, band);
+        if (lane == 0) atomicAdd(work, (unsigned)(((long)ww * ww * 16) >> 12));       // units of 4096 complex MACs
+    }
+}
+
 // Fused launches (qr_window_kernel): band end of a launch whose predecessor's band ended at e_prev -- every window of the launch and the first
 // one of the next end left of it, because the predecessor's band already reached the first window of this launch and a window step advances
 // by at most QW - 2 k - 1 columns -- and the number of 16-column strips between the two, which the chase workgroup brings up to date itself.
@@ -1080,7 +1177,7 @@ template <class T, bool DBG>
 __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__ Aall, long mstride, int n, QrState* __restrict__ st_all,
                                                         cx<T>* __restrict__ Ulog_all, QrLink* __restrict__ links_all, const cx<T>* __restrict__ shifts_all,
                                                         int par, int nslot, int kc, int slot0, int nsteps, int band_on, int* __restrict__ counters, long long* dbg_all,
-                                                        int prev_q0, int prev_nq, unsigned* __restrict__ work) {
+                                                        int prev_q0, int prev_nq, unsigned* __restrict__ work, cx<T>* __restrict__ Zall) {
     // FUSED LAUNCH (one chain per sweep, prev_nq > 0): besides the chase workgroups (blockIdx.x < kc) the grid carries FAR workgroups
     // (blockIdx.x >= kc) that apply the left update of the PREVIOUS launch's links to the columns this launch's chase does not touch -- the
     // work that sat, as a launch of its own, between two chase launches of the chain in rounds 4 - 5 (76 us alone, 207 us in situ, eleven
@@ -1096,6 +1193,19 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     T* Ur = reinterpret_cast<T*>(smem);              // [QW][MLD] x 2: split planes of U for the band update, over Hw | rlog (both dead by then)
     T* Ui = Ur + QW * MLD;
     static_assert(sizeof(T) * 2 * QW * MLD <= sizeof(cx<T>) * QW * LD + sizeof(RotCS<T>) * WMAXS * QNS, "planes fit over window + log");
+    if ((int)blockIdx.x >= kc && kc > 1) {
+        // Several chains per sweep (one window step per launch): the extra workgroups apply the PREVIOUS step's links from the right to H and to
+        // Z.  That update touches rows above and columns of the previous windows only; this launch's chase workgroups work on windows that
+        // start at or below the end of their own previous window and, for a follower, end at or above the start of the previous window of the
+        // chain ahead (the gate in the chase loop below) -- disjoint from all of it -- and the left update of the previous step, with which it
+        // shares blocks, was its own launch in between.  One launch fewer on the chain of every window step (rounds 3 - 5: window, left, right).
+        const int b = blockIdx.y, fx = (int)blockIdx.x - kc, per = ((int)gridDim.x - kc) / kc;
+        const int ch = fx / per, part = fx - ch * per;
+        const QrLink l = links_all[((long)b * nslot + prev_q0) * kc + ch];
+        right_link_strips<T>(Aall + (long)b * mstride, Zall + (long)b * mstride, n, l, Ulog_all + (((long)b * nslot + prev_q0) * kc + ch) * QW * QW, Ur, Ui,
+                             sflag + 1, 16 * part, 16 * (part + 1), band_on, work + 4);
+        return;
+    }
     if ((int)blockIdx.x >= kc) {
         const int b = blockIdx.y, fx = (int)blockIdx.x - kc, nfar = (int)gridDim.x - kc;
         if (threadIdx.x == 0) sst = st_all[b];
@@ -1136,7 +1246,7 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
     const int sb = t / LPB, j = t & (LPB - 1);       // bulge index, lane within the group
     const cx<T> shift = (sb < k) ? shifts_all[((long)b * QKC + ch) * QNS + sb] : cx<T>(T(0), T(0));
     constexpr int RPT = QW * QW / WTHREADS, RSTEP = WTHREADS / QW;      // window elements per thread, row stride between them
-    if (prev_nq > 0) {
+    if (prev_nq > 0 && kc == 1) {
         // catch-up of a fused launch: the previous launch's links on the strips between its band end and ours (see the kernel head), whether
         // or not the chain still moves; our own band then ends where the far workgroups begin
         const QrLink* pl = links_all + ((long)b * nslot + prev_q0) * kc + ch;
@@ -1160,6 +1270,12 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
                 int p0, p1, pe;
                 chain_window(ilo, ihi, st.k[ch - 1], st.tau[ch - 1][par], st.tau_last[ch - 1], p0, p1, pe);
                 if (w1 > p0) move = false;
+            }
+            if (ch > 0 && prev_nq > 0) {
+                // the previous step's right / Z update rides in THIS launch (extra workgroups, see the kernel head): it writes the columns of the
+                // PREVIOUS window of the chain ahead in the rows above it, so this chain's window must also end above that window's start
+                const QrLink pa = links_all[((long)b * nslot + prev_q0) * kc + ch - 1];
+                if (pa.kind == QRL_CHASE && w1 > pa.w0) move = false;
             }
         }
         if (!move) {
@@ -1649,6 +1765,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const bool defer = kc == 1 && K.defer != 1;
     const bool fuse = defer && K.fuse != 1;                  // fused launches: see qr_window_kernel
     const int far_wgs = cdiv_i(cdiv_i(n, 16), WTHREADS / 64);       // far workgroups per matrix: 16 strips each, all strips in one pass
+    // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse as above)
+    const bool rfuse = kc > 1 && !defer && K.fuse != 1;
+    const int rz_wgs = cdiv_i(2 * cdiv_i(n, 16), WTHREADS / 64);    // workgroups per chain: [H rows above the window | Z rows], 16 strips each
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
@@ -1751,10 +1870,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               const bool dbgk = qr_debug && G.b0 == 0;
               long long* dbp = dbgk ? dbg_dev : (long long*)nullptr;
               // fused launch: the far part of the previous launch's left update rides along (not behind slot 0, whose left update is a launch of its own)
-              const int pq = (fuse && q > 1) ? prev_q : 0, pn = (fuse && q > 1) ? prev_ns : 0;
-              const int gx = kc + (pn > 0 ? far_wgs : 0);
-              if (dbgk) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk);
-              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk);
+              // several chains: the right / Z update of the previous step rides along instead (rz_wgs workgroups per chain)
+              const bool ride = (kc == 1 ? fuse : rfuse) && q > 1;
+              const int pq = ride ? prev_q : 0, pn = ride ? prev_ns : 0;
+              const int gx = kc + (pn > 0 ? (kc == 1 ? far_wgs : kc * rz_wgs) : 0);
+              if (dbgk) TRX_LAUNCH((qr_window_kernel<T, true>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk, Zg);
+              else TRX_LAUNCH((qr_window_kernel<T, false>), dim3(gx, G.nb), dim3(WTHREADS), smw, G.s, Ag, mstride, n, stg, Ul, lk, shg, G.par, nslot, kc, q, ns, band_on, G.summary + 8, dbp, pq, pn, wk, Zg);
             }
             G.par ^= (ns & 1);
             { ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
@@ -1770,10 +1891,17 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
               // several chains: the right update of H cannot wait (the following chain's windows read rows the chain ahead has passed), and Z goes
               // with it: one or two matrices have no throughput to protect, and a deferred walk over ~170 links is a 3 ms latency chain per sweep
               // (measured: config 5 4.26 s with Z deferred against 3.98 s in round 4's two-launch form)
-              if (!defer)
+              // (rfuse: the NEXT window launch does it; slot 0 excepted -- it may hold a dense link, whose update is a launch of its own, so the
+              // launch of step 1 carries nothing, as in the one-chain form, and step 0's chase links are applied here)
+              if (!defer && (!rfuse || q == 0))
                   TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, q, ns, 1, 3, band_on); }
             prev_q = q; prev_ns = ns;
             q += ns;
+        }
+        if (rfuse && prev_q > 0) {
+            // the right / Z update of the sweep's last step
+            ProfScope p(PROF_QR_APPLY_LEFT, G.s, 0, 0);
+            TRX_LAUNCH((apply_links_kernel<T, 1>), dim3(2 * cdiv_i(n, 64), G.nb), dim3(256), sma, G.s, Ag, Zg, mstride, n, (const QrLink*)lk, (const cx<T>*)Ul, Ud, wk, nslot, kc, prev_q, prev_ns, 1, 3, band_on);
         }
         if (fuse && prev_q > 0) {
             // the left update of the sweep's last launch
