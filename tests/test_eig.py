@@ -124,11 +124,11 @@ def _set_knobs(be, **kw):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(qr_chains=2, slab_spw=2)])
+@pytest.mark.parametrize("knobs", [dict(qr_groups=3, slab_spw=4), dict(qr_groups=1, slab_spw=1, qr_aed=32), dict(qr_chains=1), dict(qr_chains=2, qr_groups=2), dict(slab_band=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(qr_chains=2, slab_spw=2), dict(qr_chains=2, qr_fuse=1), dict(qr_chains=3, qr_fuse=2)])
 def test_eig_tuning_knobs(backend, knobs):
     """The tuning knobs of the QR phase (iteration groups, strips per wave, AED window, bulge chains per sweep; include/trx.h:
     trx_tuning) select different code paths, not results."""
-    if backend == "emu" and knobs in (dict(qr_chains=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(qr_chains=2, slab_spw=2)):
+    if backend == "emu" and knobs in (dict(qr_chains=1), dict(eig_vec=1), dict(eig_vec=1, qr_groups=3, slab_band=1), dict(qr_chains=2, slab_spw=2), dict(qr_chains=3, qr_fuse=2)):
         pytest.skip("emulator time budget: one chain and Schur vectors are the automatic choices at this size, the combinations are covered knob by knob")
     be = get_backend(backend)
     n, batch = (76, 8) if backend == "emu" else (90, 9)          # batch >= 8: two iteration groups by default

@@ -1765,8 +1765,11 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const bool defer = kc == 1 && K.defer != 1;
     const bool fuse = defer && K.fuse != 1;                  // fused launches: see qr_window_kernel
     const int far_wgs = cdiv_i(cdiv_i(n, 16), WTHREADS / 64);       // far workgroups per matrix: 16 strips each, all strips in one pass
-    // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse as above)
-    const bool rfuse = kc > 1 && !defer && K.fuse != 1;
+    // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse: 1 off,
+    // 2 on at any batch size).  Automatic up to batch 16: measured (layer-solves/s, own launch / riding) batch 4: 5.28 / 5.57, 8: 11.81 / 12.49,
+    // 16: 18.38 / 19.12, config 5 (one n = 5202 matrix, three chains): 4.11 / 3.77 s per step; batch 32: 25.47 / 24.95, 48: 28.62 / 27.95 -- there
+    // the 1024-thread riders of many matrices queue for the compute units the chase workgroups need (profiles/r06_ab/r6y...).
+    const bool rfuse = kc > 1 && !defer && K.fuse != 1 && (batch <= 16 || K.fuse == 2);
     const int rz_wgs = cdiv_i(2 * cdiv_i(n, 16), WTHREADS / 64);    // workgroups per chain: [H rows above the window | Z rows], 16 strips each
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
