@@ -1094,15 +1094,16 @@ __device__ void right_link_strips(cx<T>* __restrict__ H, cx<T>* __restrict__ Z, 
     if (dense) vote[0] = 1;
     __syncthreads();
     const bool band = band_on && vote[0] == 0;
-    const int g = g0 + wave;
-    if (g < lim) {
+    int mine = 0;
+    for (int g = g0 + wave; g < lim; g += WTHREADS / 64) {
         SlabStrip<T> d;
         d.side = 1;
         if (g < nH) { d.X = H; d.a0 = 16 * g; d.lim = w0; }
         else { d.X = Z; d.a0 = 16 * (g - nH); d.lim = n; }
         band_right_strip<T>(Ur, Ui, d, n, w0, ww, lane, band);
-        if (lane == 0) atomicAdd(work, (unsigned)(((long)ww * ww * 16) >> 12));       // units of 4096 complex MACs
+        ++mine;
     }
+    if (lane == 0 && mine > 0) atomicAdd(work, (unsigned)(((long)ww * ww * 16 * mine) >> 12));       // units of 4096 complex MACs
 }
 
 // Fused launches (qr_window_kernel): band end of a launch whose predecessor's band ended at e_prev -- every window of the launch and the first
@@ -1202,8 +1203,9 @@ __global__ __launch_bounds__(WTHREADS) void qr_window_kernel(cx<T>* __restrict__
         const int b = blockIdx.y, fx = (int)blockIdx.x - kc, per = ((int)gridDim.x - kc) / kc;
         const int ch = fx / per, part = fx - ch * per;
         const QrLink l = links_all[((long)b * nslot + prev_q0) * kc + ch];
+        const int spr = 16 * ((2 * ((n + 15) >> 4) + 16 * per - 1) / (16 * per));        // strips per rider: the whole list over `per` riders, in rounds of 16
         right_link_strips<T>(Aall + (long)b * mstride, Zall + (long)b * mstride, n, l, Ulog_all + (((long)b * nslot + prev_q0) * kc + ch) * QW * QW, Ur, Ui,
-                             sflag + 1, 16 * part, 16 * (part + 1), band_on, work + 4);
+                             sflag + 1, spr * part, spr * (part + 1), band_on, work + 4);
         return;
     }
     if ((int)blockIdx.x >= kc) {
@@ -1770,7 +1772,9 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     // 16: 18.38 / 19.12, config 5 (one n = 5202 matrix, three chains): 4.11 / 3.77 s per step; batch 32: 25.47 / 24.95, 48: 28.62 / 27.95 -- there
     // the 1024-thread riders of many matrices queue for the compute units the chase workgroups need (profiles/r06_ab/r6y...).
     const bool rfuse = kc > 1 && !defer && K.fuse != 1 && (batch <= 16 || K.fuse == 2);
-    const int rz_wgs = cdiv_i(2 * cdiv_i(n, 16), WTHREADS / 64);    // workgroups per chain: [H rows above the window | Z rows], 16 strips each
+    static const int rspw_env = [] { const char* e = getenv("TRX_QR_RSPW"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 8) ? v : 0; }();
+    const int rspw = rspw_env ? rspw_env : 1;                        // strips per wave of a rider
+    const int rz_wgs = cdiv_i(2 * cdiv_i(n, 16), rspw * (WTHREADS / 64));    // riders per chain: [H rows above the window | Z rows], 16 x rspw strips each
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
     // (AED / shift preparation: one wave per matrix; window chase: one workgroup per matrix and chain) run while the updates
