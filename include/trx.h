@@ -105,9 +105,10 @@ int trx_eig_opts(int dtype, void* A, void* w, void* V, int n, int batch, int* in
  *                       launch per super-step, the right update of H and the update of Z one launch per sweep (link log of the sweep)
  *   "qr_defer"    1 = right update of H and update of Z after every super-step instead of once per sweep (TRX_QR_DEFER)   auto: once per sweep
  *                       when the sweep has one chain; with 2-3 chains the following chain reads the rows, so it is per step
- *   "qr_fuse"     1 = every update of a launch's links as its own launch, as in round 5; 2 = riding updates at any batch size (TRX_QR_FUSE)
+ *   "qr_fuse"     1 = every update of a launch's links as its own launch, as in round 5 (TRX_QR_FUSE)
  *                       auto: one chain per sweep -- the NEXT chase launch carries far workgroups that apply the left update beyond the columns the
- *                       chase reaches; several chains, batch <= 16 -- the NEXT step's chase launch carries the right / Z update of the step
+ *                       chase reaches; several chains -- the NEXT step's chase launch carries the right / Z update of the step (two strips per
+ *                       rider wave: TRX_QR_RSPW, environment only)
  *   "slab_spw"    1, 2, 4  strips per wave of the left update (TRX_SLAB_SPW)           auto: 1
  *   "slab_band"   1 = dense window unitary always (TRX_SLAB_BAND)                     auto: skip the structurally zero blocks of a chase unitary
  *   Eigenvector route of trx_eig

@@ -1767,13 +1767,14 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const bool defer = kc == 1 && K.defer != 1;
     const bool fuse = defer && K.fuse != 1;                  // fused launches: see qr_window_kernel
     const int far_wgs = cdiv_i(cdiv_i(n, 16), WTHREADS / 64);       // far workgroups per matrix: 16 strips each, all strips in one pass
-    // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse: 1 off,
-    // 2 on at any batch size).  Automatic up to batch 16: measured (layer-solves/s, own launch / riding) batch 4: 5.28 / 5.57, 8: 11.81 / 12.49,
-    // 16: 18.38 / 19.12, config 5 (one n = 5202 matrix, three chains): 4.11 / 3.77 s per step; batch 32: 25.47 / 24.95, 48: 28.62 / 27.95 -- there
-    // the 1024-thread riders of many matrices queue for the compute units the chase workgroups need (profiles/r06_ab/r6y...).
-    const bool rfuse = kc > 1 && !defer && K.fuse != 1 && (batch <= 16 || K.fuse == 2);
+    // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse: 1 off).
+    // Measured (layer-solves/s, own launch / riding with 1 / 2 / 4 strips per rider wave): batch 8: 11.81 / 12.49 / 12.49 / 11.62, 16: 18.38 / 19.07 /
+    // 19.49 / 18.44, 24: 22.36 / 22.16 / 23.89 / 22.75, 32: 25.46 / 24.89 / 26.83 / 25.79, 48: 28.63 / 27.81 / 29.14 / 29.22, config 5 (one n = 5202
+    // matrix, three chains): 4.11 / 3.77 / 3.75 / 4.53 s per step -- one strip per wave floods the chip with 1024-thread riders once many matrices
+    // are in flight, four leave the riders on the launch's critical path (profiles/r06_ab/r6y..., r6z...).
+    const bool rfuse = kc > 1 && !defer && K.fuse != 1;
     static const int rspw_env = [] { const char* e = getenv("TRX_QR_RSPW"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 8) ? v : 0; }();
-    const int rspw = rspw_env ? rspw_env : 1;                        // strips per wave of a rider
+    const int rspw = rspw_env ? rspw_env : 2;                        // strips per wave of a rider (TRX_QR_RSPW, environment only)
     const int rz_wgs = cdiv_i(2 * cdiv_i(n, 16), rspw * (WTHREADS / 64));    // riders per chain: [H rows above the window | Z rows], 16 x rspw strips each
 
     // The batch is split into groups that iterate out of phase on their own streams: the latency-bound kernels of one group
