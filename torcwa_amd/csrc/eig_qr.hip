@@ -1766,7 +1766,12 @@ int hessenberg_qr(hipStream_t s, const EigBuffers<T>& B, int n, int batch, int* 
     const int super = kc == 1 ? (K.super ? K.super : (sizeof(T) == 4 ? 4 : 8)) : 1;          // measured: fp32 4 (2 / 8 within 0.5 %), fp64 8 (28.4 vs 28.1 layer-solves/s on the all-fp64 route)
     const bool defer = kc == 1 && K.defer != 1;
     const bool fuse = defer && K.fuse != 1;                  // fused launches: see qr_window_kernel
-    const int far_wgs = cdiv_i(cdiv_i(n, 16), WTHREADS / 64);       // far workgroups per matrix: 16 strips each, all strips in one pass
+    static const int fspw_env = [] { const char* e = getenv("TRX_QR_FSPW"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 8) ? v : 0; }();
+    // Strips per wave of a far workgroup (TRX_QR_FSPW, environment only).  Measured at batch 128 (layer-solves/s; QR phase): 1 strip 36.85 (895 ms), 2:
+    // 37.40 (844 ms), 4: 37.82 (810 ms); batch 64: 31.81 / 31.86 / 31.97 -- fewer, longer far workgroups stop queueing for the compute units the
+    // chase workgroups of the four groups leave, and still end before the chase does (profiles/r06_ab/r6za_far_strips_per_wave.txt).
+    const int fspw = fspw_env ? fspw_env : 4;
+    const int far_wgs = cdiv_i(cdiv_i(n, 16), fspw * (WTHREADS / 64));       // far workgroups per matrix: 16 x fspw strips each, all strips in one pass
     // several chains per sweep: the right / Z update of a window step rides in the NEXT step's chase launch (qr_window_kernel; knob qr_fuse: 1 off).
     // Measured (layer-solves/s, own launch / riding with 1 / 2 / 4 strips per rider wave): batch 8: 11.81 / 12.49 / 12.49 / 11.62, 16: 18.38 / 19.07 /
     // 19.49 / 18.44, 24: 22.36 / 22.16 / 23.89 / 22.75, 32: 25.46 / 24.89 / 26.83 / 25.79, 48: 28.63 / 27.81 / 29.14 / 29.22, config 5 (one n = 5202
